@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference implementation.
+
+TEST INFRASTRUCTURE.  Runs only in the build container, where the reference checkout is
+mounted read-only at /root/reference (it never travels to the GPU box; the .npz fixtures
+do).  The reference is imported unmodified:
+
+    gaussian_splatting.build_sigma_from_params   gaussian_splatting/gaussian.py:71
+    gaussian_splatting.evaluate_sh               gaussian_splatting/spherical_harmonics.py:70
+    gaussian_splatting.render                    gaussian_splatting/render.py:62
+
+Each fixture stores (a) the float32-representable inputs, (b) the float64 reference image,
+(c) the six parameter gradients of L = sum(image * Wrand) in float64, (d) the float32
+reference image (the reference's own fp32-vs-fp64 disagreement = tolerance floor), and
+(e) per-stage intermediates read from render()'s frame locals at return.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py [case ...]
+"""
+import os
+import sys
+import hashlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("GS_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+import gaussian_splatting as ref  # noqa: E402  (the reference)
+from oracle import scenes  # noqa: E402
+
+REF_RENDER_MOD = sys.modules["gaussian_splatting.render"]
+OUT = os.path.join(ROOT, "tests", "golden")
+PARAMS = ["pos", "scale_raw", "q_raw", "opacity_raw", "f_dc", "f_rest"]
+
+
+class _Locals:
+    """sys.setprofile hook: copy render()'s frame locals when it returns (or raises)."""
+
+    def __init__(self):
+        self.snap = None
+        self.code = REF_RENDER_MOD.render.__code__
+
+    def __call__(self, frame, event, arg):
+        if event == "return" and frame.f_code is self.code:
+            self.snap = dict(frame.f_locals)
+
+
+def _t(x, dtype, grad=False):
+    t = torch.tensor(np.asarray(x), dtype=dtype)
+    return t.requires_grad_(grad)
+
+
+def run_fused(s, dtype, wrand=None, capture=False):
+    """The reference call sequence of scripts/train.py:463,502,505 on one view."""
+    p = {k: _t(s[k], dtype, grad=wrand is not None) for k in PARAMS}
+    c2w = _t(s["c2w"], dtype)
+    sigma = ref.build_sigma_from_params(p["scale_raw"], p["q_raw"])
+    color = ref.evaluate_sh(p["f_dc"], p["f_rest"], p["pos"], c2w)
+    hook = _Locals()
+    if capture:
+        sys.setprofile(hook)
+    try:
+        img = ref.render(p["pos"], color, p["opacity_raw"], sigma, c2w, s["H"], s["W"], s["fx"], s["fy"],
+                         s["cx"], s["cy"], **s["kwargs"])
+    finally:
+        sys.setprofile(None)
+    grads = None
+    if wrand is not None:
+        loss = (img * _t(wrand, dtype)).sum()
+        loss.backward()
+        grads = {k: (p[k].grad if p[k].grad is not None else torch.zeros_like(p[k])).numpy() for k in PARAMS}
+    return img.detach().numpy(), grads, sigma.detach().numpy(), color.detach().numpy(), hook.snap
+
+
+def intermediates(snap):
+    """Reduce render()'s locals to arrays indexed like the final (depth-sorted, on-screen) list."""
+    out = {}
+    if snap is None or "on_screen" not in snap or "inverse_covariance" not in snap:
+        return out
+    n0 = snap["opacity_mask"].numel()
+    ids = torch.arange(n0)[snap["opacity_mask"]][snap["in_guard"]][snap["keep"]][snap["order"]][snap["on_screen"]]
+    out["im_ids"] = ids.numpy().astype(np.int32)                       # original Gaussian index
+    out["im_u"] = snap["u"].detach().numpy()
+    out["im_v"] = snap["v"].detach().numpy()
+    out["im_cov2d"] = snap["sigma_camera"].detach().numpy()            # after eigen clamp
+    out["im_conic"] = snap["inverse_covariance"].detach().numpy()      # after det / diag clamp
+    out["im_evals"] = snap["evals"][snap["on_screen"]].detach().numpy()
+    out["im_opacity"] = snap["opacity"].detach().numpy()
+    out["im_color"] = snap["color"].detach().numpy()
+    out["im_tile_rect"] = torch.stack([snap["umin_tile"], snap["vmin_tile"], snap["umax_tile"],
+                                       snap["vmax_tile"]], 1).numpy().astype(np.int32)
+    out["im_pair_gauss"] = snap["gaussian_ids"].numpy().astype(np.int32)   # index into the final list
+    out["im_tile_ids"] = snap["unique_tile_ids"].numpy().astype(np.int32)
+    out["im_tile_start"] = snap["start"].numpy().astype(np.int32)
+    out["im_tile_end"] = snap["end"].numpy().astype(np.int32)
+    return out
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"  wrote {os.path.relpath(path, ROOT)}  {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def scene_arrays(s):
+    d = {k: np.asarray(s[k], dtype=np.float32) for k in PARAMS}
+    d["c2w"] = np.asarray(s["c2w"], dtype=np.float32)
+    d["cam"] = np.array([s["H"], s["W"], s["fx"], s["fy"], s["cx"], s["cy"]], dtype=np.float64)
+    kw = s["kwargs"]
+    d["kw_names"] = np.array(sorted(kw.keys()))
+    d["kw_vals"] = np.array([kw[k] for k in sorted(kw.keys())], dtype=np.float64)
+    return d
+
+
+def gen_case(name):
+    print(name)
+    s = scenes.CASES[name]()
+    rng = np.random.default_rng(int(hashlib.sha1(name.encode()).hexdigest()[:8], 16))
+    wrand = rng.uniform(0.0, 1.0, (s["H"], s["W"], 3))
+    arrs = scene_arrays(s)
+    arrs["wrand"] = wrand
+    if name == "g10_offscreen":
+        try:
+            run_fused(s, torch.float64)
+            raise SystemExit("expected the reference to raise for " + name)
+        except Exception as e:  # the reference raises a bare Exception (render.py:236)
+            arrs["raises"] = np.array(str(e))
+            print("  reference raised:", e)
+        save(name, **arrs)
+        return
+    img64, g64, sigma64, color64, snap = run_fused(s, torch.float64, wrand, capture=True)
+    img32, g32, _, _, _ = run_fused(s, torch.float32, wrand)
+    arrs["image"] = img64
+    arrs["image_f32"] = img32.astype(np.float32)
+    arrs["sigma"] = sigma64
+    arrs["color"] = color64
+    for k in PARAMS:
+        arrs["grad_" + k] = g64[k]
+        arrs["grad32_" + k] = g32[k].astype(np.float32)
+        if not np.isfinite(g64[k]).all():
+            raise SystemExit(f"{name}: non-finite reference gradient for {k} (degenerate eigenvalues?)")
+    arrs.update(intermediates(snap))
+    d = np.abs(img64 - img32)
+    nv = len(arrs.get("im_ids", []))
+    npairs = len(arrs.get("im_pair_gauss", []))
+    print(f"  image mean {img64.mean():.4f} max {img64.max():.4f}  V={nv} P={npairs} "
+          f"fp32-vs-fp64 max {d.max():.2e} (> 1e-5: {(d > 1e-5).sum()} values)")
+    for k in PARAMS:
+        den = np.linalg.norm(g64[k]) + 1e-300
+        print(f"    grad {k:12s} |g|={den:.3e}  fp32 rel-L2 err {np.linalg.norm(g64[k] - g32[k]) / den:.2e}")
+    save(name, **arrs)
+
+
+def gen_unfused():
+    """G11: render() called directly with arbitrary colour / covariance (the un-fused boundary)."""
+    name = "g11_unfused"
+    print(name)
+    rng = np.random.default_rng(211)
+    s = scenes._base(rng, 500, 64, 96, 80.0, 80.0, 48.0, 32.0)
+    N = 500
+    A = rng.normal(0, 0.12, (N, 3, 3))
+    sigma = (A @ A.transpose(0, 2, 1) + 1e-4 * np.eye(3)).astype(np.float32)
+    sigma = 0.5 * (sigma + sigma.transpose(0, 2, 1))
+    color = rng.uniform(-0.4, 1.6, (N, 3)).astype(np.float32)     # outside [0,1]: exercises the output clamp mask
+    wrand = rng.uniform(0.0, 1.0, (s["H"], s["W"], 3))
+    outs = {}
+    for dtype, tag in ((torch.float64, ""), (torch.float32, "32")):
+        pos = _t(s["pos"], dtype, True)
+        col = _t(color, dtype, True)
+        opa = _t(s["opacity_raw"], dtype, True)
+        sig = _t(sigma, dtype, True)
+        img = ref.render(pos, col, opa, sig, _t(s["c2w"], dtype), s["H"], s["W"], s["fx"], s["fy"], s["cx"], s["cy"])
+        (img * _t(wrand, dtype)).sum().backward()
+        outs["image" + ("_f32" if tag else "")] = img.detach().numpy()
+        for k, t in (("pos", pos), ("color", col), ("opacity_raw", opa), ("sigma", sig)):
+            outs[f"grad{tag}_{k}"] = t.grad.numpy()
+    arrs = scene_arrays(s)
+    arrs.update(outs, sigma_in=sigma, color_in=color, wrand=wrand)
+    print(f"  image mean {outs['image'].mean():.4f}  clamped-high values {(outs['image'] >= 1).sum()} "
+          f"clamped-low {(outs['image'] <= 0).sum()}")
+    save(name, **arrs)
+
+
+def gen_pieces():
+    """Stand-alone goldens for the small exported functions (forward + backward), float64."""
+    print("pieces")
+    rng = np.random.default_rng(311)
+    N = 64
+    scale_raw = rng.normal(-2, 1.5, (N, 3)).astype(np.float32)
+    scale_raw[:4] = -15.0                                  # exp() < 1e-6 -> clamp_min branch
+    q_raw = rng.normal(0, 1, (N, 4)).astype(np.float32)
+    f_dc = rng.normal(0, 1, (N, 3)).astype(np.float32)
+    f_rest = rng.normal(0, 0.5, (N, 45)).astype(np.float32)
+    pts = rng.normal(0, 2, (N, 3)).astype(np.float32)
+    c2w = scenes._camera(rng)
+    m2 = rng.normal(0, 1, (N, 2, 2)).astype(np.float32)
+    w_sigma = rng.normal(0, 1, (N, 3, 3))
+    w_col = rng.normal(0, 1, (N, 3))
+    w_rot = rng.normal(0, 1, (N, 3, 3))
+    d = torch.float64
+    sr, qr = _t(scale_raw, d, True), _t(q_raw, d, True)
+    sig = ref.build_sigma_from_params(sr, qr)
+    (sig * _t(w_sigma, d)).sum().backward()
+    fd, fr, pt = _t(f_dc, d, True), _t(f_rest, d, True), _t(pts, d, True)
+    col = ref.evaluate_sh(fd, fr, pt, _t(c2w, d))
+    (col * _t(w_col, d)).sum().backward()
+    qq = _t(q_raw, d, True)
+    rot = ref.quat_to_rotmat(qq)
+    (rot * _t(w_rot, d)).sum().backward()
+    inv = ref.inv2x2(_t(m2, d))
+    H, W, Hs, Ws = 540, 960, 1080, 1920
+    si = np.array(ref.scale_intrinsics(H, W, Hs, Ws, 1100.0, 1090.0, 961.5, 538.25))
+    uv, x, y, z = ref.project_points(_t(pts, d), _t(c2w, d), 500.0, 510.0, 320.0, 240.0)
+    save("pieces", scale_raw=scale_raw, q_raw=q_raw, f_dc=f_dc, f_rest=f_rest, points=pts, c2w=c2w, m2=m2,
+         w_sigma=w_sigma, w_col=w_col, w_rot=w_rot, sigma=sig.detach().numpy(), grad_scale_raw=sr.grad.numpy(),
+         grad_q_raw=qr.grad.numpy(), color=col.detach().numpy(), grad_f_dc=fd.grad.numpy(),
+         grad_f_rest=fr.grad.numpy(), grad_points=pt.grad.numpy(), rot=rot.detach().numpy(),
+         grad_q_rot=qq.grad.numpy(), inv2x2=inv.numpy(), scale_intrinsics=si,
+         harmonics_names=np.array(sorted(ref.HARMONICS)), harmonics_vals=np.array(
+             [ref.HARMONICS[k] for k in sorted(ref.HARMONICS)]),
+         proj_uv=uv.numpy(), proj_xyz=torch.stack([x, y, z], 1).numpy())
+
+
+def gen_config1():
+    """G12: config 1 at full size (10k Gaussians, 256x256, f_rest = 0): image + gradient digests."""
+    name = "g13_config1_full"
+    print(name)
+    s = scenes.synthetic_scene(1)
+    wrand = np.random.default_rng(1).uniform(0, 1, (s["H"], s["W"], 3)).astype(np.float32)
+    img64, g64, _, _, snap = run_fused(s, torch.float64, wrand.astype(np.float64), capture=True)
+    im = intermediates(snap)
+    blk = img64.reshape(s["H"] // 2, 2, s["W"] // 2, 2, 3).mean(axis=(1, 3))
+    arrs = dict(image_blockmean=blk.astype(np.float32), image_rows8=img64[::8].astype(np.float32),
+                wrand_seed=np.array(1),
+                input_digest=np.array([float(np.abs(s[k]).astype(np.float64).sum()) for k in PARAMS]),
+                V=np.array(len(im["im_ids"])), P=np.array(len(im["im_pair_gauss"])))
+    for k in PARAMS:
+        g = g64[k]
+        arrs["gnorm_" + k] = np.array(np.linalg.norm(g))
+        arrs["grad_" + k + "_head"] = g[:1024].astype(np.float32)
+    print(f"  V={arrs['V']} P={arrs['P']} image mean {img64.mean():.4f}")
+    save(name, **arrs)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    want = sys.argv[1:]
+    for n in scenes.CASES:
+        if not want or n in want:
+            gen_case(n)
+    if not want or "g11_unfused" in want:
+        gen_unfused()
+    if not want or "pieces" in want:
+        gen_pieces()
+    if not want or "g13_config1_full" in want:
+        gen_config1()
