@@ -1,0 +1,199 @@
+// gs_body.h -- per-Gaussian thread bodies of the projection kernels (forward K1, backward K7) and of the
+// two stand-alone ops.  Shared by gsplat_kernels.hip (device) and host_math_check.cpp (host unit test).
+#pragma once
+#include "../../include/gsplat_mi355x.h"
+#include "gs_math.h"
+
+namespace gsm {
+
+struct alignas(16) f4 { float x, y, z, w; };
+
+GS_HD uint32_t f2u(float f) { union { float f; uint32_t u; } c; c.f = f; return c.u; }
+GS_HD float u2f(uint32_t u) { union { float f; uint32_t u; } c; c.u = u; return c.f; }
+
+// Projected record, 48 B per Gaussian in three 16-B streams (SoA of float4):
+//   rec0 = (u, v, A11, A12)   rec1 = (A22, opacity, r, g)   rec2 = (b, depth z, rect lo, rect hi)
+// rect lo = tx0 | ty0 << 16, rect hi = tx1 | ty1 << 16 (inclusive tile rectangle).
+struct Records {
+    f4* rec0;
+    f4* rec1;
+    f4* rec2;
+    uint32_t* tiles;      // tiles touched per Gaussian (0 = not visible)
+};
+
+GS_HD ViewK make_viewk(const gsplat_view& v) {
+    ViewK k;
+    k.fx = v.fx; k.fy = v.fy; k.cx = v.cx; k.cy = v.cy;
+    k.near_z = v.near_z; k.far_z = v.far_z;
+    // computed in double like the Python scalars of utils.py:82-91, then rounded once
+    k.gl = (float)(-(double)v.pix_guard - (double)v.cx);
+    k.gr = (float)((double)v.W + (double)v.pix_guard - (double)v.cx);
+    k.gt = (float)(-(double)v.pix_guard - (double)v.cy);
+    k.gb = (float)((double)v.H + (double)v.pix_guard - (double)v.cy);
+    k.opacity_min = (float)((double)v.alpha_cutoff * 0.5);
+    k.min_conis = v.min_conis; k.chi_clip = v.chi_square_clip; k.alpha_max = v.alpha_max; k.alpha_cutoff = v.alpha_cutoff;
+    k.H = v.H; k.W = v.W; k.tile = v.tile;
+    k.tiles_x = (v.W + v.tile - 1) / v.tile; k.tiles_y = (v.H + v.tile - 1) / v.tile;
+    return k;
+}
+
+// Coefficient access in the reference layout: basis 0 from f_dc[N,3], bases 1..15 from f_rest[N,45] channel-major.
+struct ShCoefGlobal {
+    const float* dc;      // &f_dc[i*3]
+    const float* rest;    // &f_rest[i*45]
+    GS_HD float operator()(int k, int ch) const { return k == 0 ? dc[ch] : rest[ch * 15 + (k - 1)]; }
+};
+
+GS_HD void load_cov6(const float* sigma9, float S[6]) {
+    // symmetrised: the projected 2x2 is symmetrised by the reference (render.py:175), which equals projecting sym(Sigma)
+    S[0] = sigma9[0]; S[1] = 0.5f * (sigma9[1] + sigma9[3]); S[2] = 0.5f * (sigma9[2] + sigma9[6]);
+    S[3] = sigma9[4]; S[4] = 0.5f * (sigma9[5] + sigma9[7]); S[5] = sigma9[8];
+}
+
+// K1 body.  Returns the VIS_* code; writes the record and tiles[i].
+template <class Coef>
+GS_HD int project_one(int64_t i, const gsplat_gaussians& g, bool fused, Coef coef, const Camera& cam, const ViewK& vk,
+                      const Records& out) {
+    const float p[3] = {g.pos[i * 3 + 0], g.pos[i * 3 + 1], g.pos[i * 3 + 2]};
+    float S[6];
+    if (fused) {
+        const float sr[3] = {g.scale_raw[i * 3 + 0], g.scale_raw[i * 3 + 1], g.scale_raw[i * 3 + 2]};
+        const float qr[4] = {g.q_raw[i * 4 + 0], g.q_raw[i * 4 + 1], g.q_raw[i * 4 + 2], g.q_raw[i * 4 + 3]};
+        CovMid cm;
+        cov_from_params(sr, qr, S, cm);
+    } else {
+        load_cov6(g.sigma + i * 9, S);
+    }
+    Proj o; ProjMid m;
+    project_gaussian(p, S, g.opacity_raw[i], cam, vk, o, m);
+    uint32_t nt = 0;
+    if (o.vis == VIS_OK) {
+        float rgb[3];
+        if (fused) {
+            ShMid sm;
+            sh_basis(p, cam.eye, sm);
+            sh_colour(sm, coef, rgb);
+        } else {
+            rgb[0] = g.color[i * 3 + 0]; rgb[1] = g.color[i * 3 + 1]; rgb[2] = g.color[i * 3 + 2];
+        }
+        nt = (uint32_t)((o.tx1 - o.tx0 + 1) * (o.ty1 - o.ty0 + 1));
+        out.rec0[i] = f4{o.u, o.v, o.A11, o.A12};
+        out.rec1[i] = f4{o.A22, o.opacity, rgb[0], rgb[1]};
+        out.rec2[i] = f4{rgb[2], o.z, u2f((uint32_t)o.tx0 | ((uint32_t)o.ty0 << 16)), u2f((uint32_t)o.tx1 | ((uint32_t)o.ty1 << 16))};
+    }
+    out.tiles[i] = nt;
+    return o.vis;
+}
+
+// K7 body.  grad2d row = (g_u, g_v, g_A11, g_A12, g_A22, g_opacity, g_r, g_g, g_b, ...), 16 floats per Gaussian.
+// emit_rest(k, ch, val) receives dL/d(SH coefficient) for k = 0..15 (k = 0 -> f_dc).  Every output row is written.
+template <class Coef, class Emit>
+GS_HD void project_backward_one(int64_t i, const gsplat_gaussians& g, bool fused, Coef coef, Emit emit_sh, const Camera& cam,
+                                const ViewK& vk, const uint32_t* tiles, const float* grad2d,
+                                const gsplat_gaussian_grads& out) {
+    float gp[3] = {0.f, 0.f, 0.f}, GS[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, go = 0.f, gsr[3] = {0, 0, 0}, gq[4] = {0, 0, 0, 0};
+    float grgb[3] = {0, 0, 0};
+    const bool vis = tiles[i] != 0;
+    if (vis) {
+        const float p[3] = {g.pos[i * 3 + 0], g.pos[i * 3 + 1], g.pos[i * 3 + 2]};
+        float S[6];
+        CovMid cm;
+        float sr[3], qr[4];
+        if (fused) {
+            sr[0] = g.scale_raw[i * 3 + 0]; sr[1] = g.scale_raw[i * 3 + 1]; sr[2] = g.scale_raw[i * 3 + 2];
+            qr[0] = g.q_raw[i * 4 + 0]; qr[1] = g.q_raw[i * 4 + 1]; qr[2] = g.q_raw[i * 4 + 2]; qr[3] = g.q_raw[i * 4 + 3];
+            cov_from_params(sr, qr, S, cm);
+        } else {
+            load_cov6(g.sigma + i * 9, S);
+        }
+        Proj o; ProjMid m;
+        project_gaussian(p, S, g.opacity_raw[i], cam, vk, o, m);
+        const float* r = grad2d + i * 16;
+        project_gaussian_backward(m, o, cam, vk, r[0], r[1], r[2], r[3], r[4], r[5], gp, GS, go);
+        grgb[0] = r[6]; grgb[1] = r[7]; grgb[2] = r[8];
+        if (fused) {
+            cov_from_params_backward(qr, cm, GS, gsr, gq);
+            ShMid sm;
+            sh_basis(p, cam.eye, sm);
+            float rgb[3];
+            sh_colour(sm, coef, rgb);
+            float gps[3];
+            sh_colour_backward(sm, coef, rgb, grgb, emit_sh, gps);
+            gp[0] += gps[0]; gp[1] += gps[1]; gp[2] += gps[2];
+        }
+    } else if (fused) {
+        for (int k = 0; k < 16; ++k)
+            for (int ch = 0; ch < 3; ++ch) emit_sh(k, ch, 0.f);
+    }
+    out.pos[i * 3 + 0] = gp[0]; out.pos[i * 3 + 1] = gp[1]; out.pos[i * 3 + 2] = gp[2];
+    out.opacity_raw[i] = go;
+    if (fused) {
+        for (int k = 0; k < 3; ++k) out.scale_raw[i * 3 + k] = gsr[k];
+        for (int k = 0; k < 4; ++k) out.q_raw[i * 4 + k] = gq[k];
+    } else {
+        for (int k = 0; k < 9; ++k) out.sigma[i * 9 + k] = GS[k];
+        for (int k = 0; k < 3; ++k) out.color[i * 3 + k] = grgb[k];
+    }
+}
+
+// Stand-alone build_sigma_from_params (gaussian.py:71-127) and its backward.
+GS_HD void build_sigma_one(int64_t i, const float* scale_raw, const float* q_raw, float* sigma) {
+    const float sr[3] = {scale_raw[i * 3 + 0], scale_raw[i * 3 + 1], scale_raw[i * 3 + 2]};
+    const float qr[4] = {q_raw[i * 4 + 0], q_raw[i * 4 + 1], q_raw[i * 4 + 2], q_raw[i * 4 + 3]};
+    float S[6]; CovMid cm;
+    cov_from_params(sr, qr, S, cm);
+    float* o = sigma + i * 9;
+    o[0] = S[0]; o[1] = S[1]; o[2] = S[2]; o[3] = S[1]; o[4] = S[3]; o[5] = S[4]; o[6] = S[2]; o[7] = S[4]; o[8] = S[5];
+}
+
+GS_HD void build_sigma_backward_one(int64_t i, const float* scale_raw, const float* q_raw, const float* grad_sigma,
+                                    float* g_scale_raw, float* g_q_raw) {
+    const float sr[3] = {scale_raw[i * 3 + 0], scale_raw[i * 3 + 1], scale_raw[i * 3 + 2]};
+    const float qr[4] = {q_raw[i * 4 + 0], q_raw[i * 4 + 1], q_raw[i * 4 + 2], q_raw[i * 4 + 3]};
+    float S[6]; CovMid cm;
+    cov_from_params(sr, qr, S, cm);
+    // Sigma = R D R^T is symmetric in its own formula: only the symmetric part of the incoming gradient matters
+    const float* gi = grad_sigma + i * 9;
+    float G[9];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) G[a * 3 + b] = 0.5f * (gi[a * 3 + b] + gi[b * 3 + a]);
+    float gs[3], gq[4];
+    cov_from_params_backward(qr, cm, G, gs, gq);
+    for (int k = 0; k < 3; ++k) g_scale_raw[i * 3 + k] = gs[k];
+    for (int k = 0; k < 4; ++k) g_q_raw[i * 4 + k] = gq[k];
+}
+
+// Stand-alone evaluate_sh (spherical_harmonics.py:70-166) and its backward.
+GS_HD void evaluate_sh_one(int64_t i, const float* f_dc, const float* f_rest, const float* points, const Camera& cam,
+                           float* color) {
+    const float p[3] = {points[i * 3 + 0], points[i * 3 + 1], points[i * 3 + 2]};
+    ShMid sm;
+    sh_basis(p, cam.eye, sm);
+    float rgb[3];
+    sh_colour(sm, ShCoefGlobal{f_dc + i * 3, f_rest + i * 45}, rgb);
+    color[i * 3 + 0] = rgb[0]; color[i * 3 + 1] = rgb[1]; color[i * 3 + 2] = rgb[2];
+}
+
+struct ShEmitGlobal {
+    float* dc;      // &grad_f_dc[i*3]
+    float* rest;    // &grad_f_rest[i*45]
+    GS_HD void operator()(int k, int ch, float v) const {
+        if (k == 0) dc[ch] = v; else rest[ch * 15 + (k - 1)] = v;
+    }
+};
+
+GS_HD void evaluate_sh_backward_one(int64_t i, const float* f_dc, const float* f_rest, const float* points, const Camera& cam,
+                                    const float* grad_color, float* g_f_dc, float* g_f_rest, float* g_points) {
+    const float p[3] = {points[i * 3 + 0], points[i * 3 + 1], points[i * 3 + 2]};
+    ShMid sm;
+    sh_basis(p, cam.eye, sm);
+    ShCoefGlobal coef{f_dc + i * 3, f_rest + i * 45};
+    float rgb[3];
+    sh_colour(sm, coef, rgb);
+    const float gc[3] = {grad_color[i * 3 + 0], grad_color[i * 3 + 1], grad_color[i * 3 + 2]};
+    float gp[3];
+    sh_colour_backward(sm, coef, rgb, gc, ShEmitGlobal{g_f_dc + i * 3, g_f_rest + i * 45}, gp);
+    g_points[i * 3 + 0] = gp[0]; g_points[i * 3 + 1] = gp[1]; g_points[i * 3 + 2] = gp[2];
+}
+
+}  // namespace gsm

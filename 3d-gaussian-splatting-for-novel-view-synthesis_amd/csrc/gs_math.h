@@ -1,0 +1,389 @@
+// gs_math.h -- per-Gaussian math of the projection stage (forward and analytic backward), fp32.
+//
+// Product code.  The functions are `__host__ __device__` so the same source that the HIP kernels
+// inline can be compiled by g++ into a host test library (csrc/host_math_check.cpp) and checked
+// against the oracle on a machine without a GPU.  That host build is a TEST of this file; it is
+// never used as a fallback for the product path.
+//
+// Stage ids (F*/B*) refer to SURVEY.md §8(a); reference lines are cited per function.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define GS_HD __host__ __device__ __forceinline__
+#else
+#define GS_HD inline
+#endif
+
+namespace gsm {
+
+// Camera block derived on the device from c2w (utils.py:25-29); read uniformly by every thread.
+struct Camera {
+    float w[9];     // Rwc = c2w[:3,:3]^T, row-major
+    float t[3];     // -Rwc * c2w[:3,3]
+    float eye[3];   // c2w[:3,3] (camera centre; spherical_harmonics.py:132)
+    float pad;
+};
+
+// Scalars of one view, prepared on the host from gsplat_view.
+struct ViewK {
+    float fx, fy, cx, cy;
+    float near_z, far_z;
+    float gl, gr, gt, gb;       // guard-band bounds: -g-cx, W+g-cx, -g-cy, H+g-cy (utils.py:82-91)
+    float opacity_min;          // alpha_cutoff * 0.5 (render.py:107)
+    float min_conis, chi_clip, alpha_max, alpha_cutoff;
+    int32_t H, W, tiles_x, tiles_y, tile;
+};
+
+enum : int { VIS_OK = 0, VIS_CULLED = 1, VIS_OFFSCREEN = 2 };
+
+GS_HD float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+GS_HD float clampf_(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+
+GS_HD void build_camera(const float* c2w, Camera& c) {
+    // w2c = [R^T | -R^T t]  (utils.py:25-29)
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c.w[i * 3 + j] = c2w[j * 4 + i];
+    for (int i = 0; i < 3; ++i) {
+        c.eye[i] = c2w[i * 4 + 3];
+    }
+    for (int i = 0; i < 3; ++i) c.t[i] = -(c.w[i * 3 + 0] * c.eye[0] + c.w[i * 3 + 1] * c.eye[1] + c.w[i * 3 + 2] * c.eye[2]);
+    c.pad = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// F1 + F2: world covariance from (scale_raw, q_raw).  gaussian.py:24-68 (x,y,z,w quaternion),
+// gaussian.py:115-127.  Output: symmetric S as (xx, xy, xz, yy, yz, zz).
+// ---------------------------------------------------------------------------------------------
+struct CovMid {
+    float s[3];        // clamped scales
+    float e[3];        // exp(scale_raw)
+    float q[4];        // normalised quaternion
+    float qn;          // |q_raw|
+    float R[9];
+};
+
+GS_HD void quat_to_rot(const float q[4], float R[9]) {
+    const float x = q[0], y = q[1], z = q[2], w = q[3];
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z, xw = x * w, yw = y * w, zw = z * w;
+    R[0] = 1.f - 2.f * (yy + zz); R[1] = 2.f * (xy - zw);       R[2] = 2.f * (xz + yw);
+    R[3] = 2.f * (xy + zw);       R[4] = 1.f - 2.f * (xx + zz); R[5] = 2.f * (yz - xw);
+    R[6] = 2.f * (xz - yw);       R[7] = 2.f * (yz + xw);       R[8] = 1.f - 2.f * (xx + yy);
+}
+
+GS_HD void cov_from_params(const float scale_raw[3], const float q_raw[4], float S[6], CovMid& m) {
+    for (int k = 0; k < 3; ++k) { m.e[k] = expf(scale_raw[k]); m.s[k] = fmaxf(m.e[k], 1e-6f); }
+    m.qn = sqrtf(q_raw[0] * q_raw[0] + q_raw[1] * q_raw[1] + q_raw[2] * q_raw[2] + q_raw[3] * q_raw[3]);
+    const float inv = 1.0f / (m.qn + 1e-9f);
+    for (int k = 0; k < 4; ++k) m.q[k] = q_raw[k] * inv;
+    quat_to_rot(m.q, m.R);
+    const float d0 = m.s[0] * m.s[0], d1 = m.s[1] * m.s[1], d2 = m.s[2] * m.s[2];
+    const float* R = m.R;
+    S[0] = R[0] * R[0] * d0 + R[1] * R[1] * d1 + R[2] * R[2] * d2;
+    S[1] = R[0] * R[3] * d0 + R[1] * R[4] * d1 + R[2] * R[5] * d2;
+    S[2] = R[0] * R[6] * d0 + R[1] * R[7] * d1 + R[2] * R[8] * d2;
+    S[3] = R[3] * R[3] * d0 + R[4] * R[4] * d1 + R[5] * R[5] * d2;
+    S[4] = R[3] * R[6] * d0 + R[4] * R[7] * d1 + R[5] * R[8] * d2;
+    S[5] = R[6] * R[6] * d0 + R[7] * R[7] * d1 + R[8] * R[8] * d2;
+}
+
+// B3 (covariance part).  G = dL/dS as a full symmetric 3x3 (row-major 9), i.e. dL = sum_ij G_ij dS_ij.
+GS_HD void cov_from_params_backward(const float q_raw[4], const CovMid& m, const float G[9], float g_scale_raw[3],
+                                    float g_q_raw[4]) {
+    const float* R = m.R;
+    const float d[3] = {m.s[0] * m.s[0], m.s[1] * m.s[1], m.s[2] * m.s[2]};
+    // GR = G * R ; dL/dR = 2 * GR * D ; dL/dD_k = (R^T G R)_kk
+    float GR[9];
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) GR[i * 3 + k] = G[i * 3 + 0] * R[0 + k] + G[i * 3 + 1] * R[3 + k] + G[i * 3 + 2] * R[6 + k];
+    float dR[9];
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) dR[i * 3 + k] = 2.f * GR[i * 3 + k] * d[k];
+    for (int k = 0; k < 3; ++k) {
+        const float dD = R[0 + k] * GR[0 + k] + R[3 + k] * GR[3 + k] + R[6 + k] * GR[6 + k];
+        const float ds = 2.f * m.s[k] * dD;
+        g_scale_raw[k] = (m.e[k] >= 1e-6f) ? ds * m.e[k] : 0.f;
+    }
+    const float x = m.q[0], y = m.q[1], z = m.q[2], w = m.q[3];
+    float dq[4];
+    dq[0] = 2.f * (y * (dR[1] + dR[3]) + z * (dR[2] + dR[6]) - 2.f * x * (dR[4] + dR[8]) + w * (dR[7] - dR[5]));
+    dq[1] = 2.f * (x * (dR[1] + dR[3]) + z * (dR[5] + dR[7]) - 2.f * y * (dR[0] + dR[8]) + w * (dR[2] - dR[6]));
+    dq[2] = 2.f * (x * (dR[2] + dR[6]) + y * (dR[5] + dR[7]) - 2.f * z * (dR[0] + dR[4]) + w * (dR[3] - dR[1]));
+    dq[3] = 2.f * (x * (dR[7] - dR[5]) + y * (dR[2] - dR[6]) + z * (dR[3] - dR[1]));
+    // q = q_raw / (n + eps)
+    const float ne = m.qn + 1e-9f;
+    const float dot = dq[0] * q_raw[0] + dq[1] * q_raw[1] + dq[2] * q_raw[2] + dq[3] * q_raw[3];
+    const float c = (m.qn > 0.f) ? dot / (m.qn * ne * ne) : 0.f;
+    for (int k = 0; k < 4; ++k) g_q_raw[k] = dq[k] / ne - q_raw[k] * c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// F3: view-dependent colour.  spherical_harmonics.py:118-166.  f_rest is channel-major.
+// ---------------------------------------------------------------------------------------------
+#define GS_K0 0.28209479177387814f
+#define GS_K1 0.4886025119029199f
+#define GS_K2A 1.0925484305920792f
+#define GS_K2B 0.31539156525252005f
+#define GS_K2C 0.5462742152960396f
+#define GS_K3A 0.5900435899266435f
+#define GS_K3B 2.890611442640554f
+#define GS_K3C 0.4570457994644658f
+#define GS_K3D 0.3731763325901154f
+#define GS_K3E 1.445305721320277f
+
+struct ShMid {
+    float d[3];     // unit view direction
+    float v[3];     // p - eye
+    float n;        // |v|
+    float Y[16];
+};
+
+GS_HD void sh_basis(const float p[3], const float eye[3], ShMid& m) {
+    m.v[0] = p[0] - eye[0]; m.v[1] = p[1] - eye[1]; m.v[2] = p[2] - eye[2];
+    m.n = sqrtf(m.v[0] * m.v[0] + m.v[1] * m.v[1] + m.v[2] * m.v[2]);
+    const float inv = 1.0f / (m.n + 1e-8f);
+    const float x = m.v[0] * inv, y = m.v[1] * inv, z = m.v[2] * inv;
+    m.d[0] = x; m.d[1] = y; m.d[2] = z;
+    const float xx = x * x, yy = y * y, zz = z * z;
+    float* Y = m.Y;
+    Y[0] = GS_K0;
+    Y[1] = -GS_K1 * y; Y[2] = GS_K1 * z; Y[3] = -GS_K1 * x;
+    Y[4] = GS_K2A * x * y; Y[5] = GS_K2A * y * z; Y[6] = GS_K2B * (3.f * zz - 1.f); Y[7] = GS_K2A * x * z;
+    Y[8] = GS_K2C * (xx - yy);
+    Y[9] = GS_K3A * y * (3.f * xx - yy); Y[10] = GS_K3B * x * y * z; Y[11] = GS_K3C * y * (4.f * zz - xx - yy);
+    Y[12] = GS_K3D * z * (2.f * zz - 3.f * xx - 3.f * yy); Y[13] = GS_K3C * x * (4.f * zz - xx - yy);
+    Y[14] = GS_K3E * z * (xx - yy); Y[15] = GS_K3A * x * (xx - 3.f * yy);
+}
+
+// coef(k, ch) returns the SH coefficient of basis k, channel ch.
+template <class Coef>
+GS_HD void sh_colour(const ShMid& m, Coef coef, float rgb[3]) {
+    for (int ch = 0; ch < 3; ++ch) {
+        float acc = 0.f;
+        for (int k = 0; k < 16; ++k) acc += coef(k, ch) * m.Y[k];
+        rgb[ch] = sigmoidf_(acc);
+    }
+}
+
+// B3 (colour part).  g_rgb = dL/d colour.  Emits dL/dcoef through `emit(k, ch, value)`; returns dL/dp in g_p.
+template <class Coef, class Emit>
+GS_HD void sh_colour_backward(const ShMid& m, Coef coef, const float rgb[3], const float g_rgb[3], Emit emit, float g_p[3]) {
+    float dY[16];
+    for (int k = 0; k < 16; ++k) dY[k] = 0.f;
+    for (int ch = 0; ch < 3; ++ch) {
+        const float dpre = g_rgb[ch] * rgb[ch] * (1.f - rgb[ch]);
+        for (int k = 0; k < 16; ++k) {
+            emit(k, ch, dpre * m.Y[k]);
+            dY[k] += dpre * coef(k, ch);
+        }
+    }
+    const float x = m.d[0], y = m.d[1], z = m.d[2];
+    const float xx = x * x, yy = y * y, zz = z * z;
+    float dd[3];
+    dd[0] = -GS_K1 * dY[3] + GS_K2A * y * dY[4] + GS_K2A * z * dY[7] + 2.f * GS_K2C * x * dY[8] + 6.f * GS_K3A * x * y * dY[9] +
+            GS_K3B * y * z * dY[10] - 2.f * GS_K3C * x * y * dY[11] - 6.f * GS_K3D * x * z * dY[12] +
+            GS_K3C * (4.f * zz - 3.f * xx - yy) * dY[13] + 2.f * GS_K3E * x * z * dY[14] + GS_K3A * (3.f * xx - 3.f * yy) * dY[15];
+    dd[1] = -GS_K1 * dY[1] + GS_K2A * x * dY[4] + GS_K2A * z * dY[5] - 2.f * GS_K2C * y * dY[8] +
+            GS_K3A * (3.f * xx - 3.f * yy) * dY[9] + GS_K3B * x * z * dY[10] + GS_K3C * (4.f * zz - xx - 3.f * yy) * dY[11] -
+            6.f * GS_K3D * y * z * dY[12] - 2.f * GS_K3C * x * y * dY[13] - 2.f * GS_K3E * y * z * dY[14] -
+            6.f * GS_K3A * x * y * dY[15];
+    dd[2] = GS_K1 * dY[2] + GS_K2A * y * dY[5] + 6.f * GS_K2B * z * dY[6] + GS_K2A * x * dY[7] + GS_K3B * x * y * dY[10] +
+            8.f * GS_K3C * y * z * dY[11] + GS_K3D * (6.f * zz - 3.f * xx - 3.f * yy) * dY[12] + 8.f * GS_K3C * x * z * dY[13] +
+            GS_K3E * (xx - yy) * dY[14];
+    // d = v / (n + eps)
+    const float ne = m.n + 1e-8f;
+    const float dot = dd[0] * m.v[0] + dd[1] * m.v[1] + dd[2] * m.v[2];
+    const float c = (m.n > 0.f) ? dot / (m.n * ne * ne) : 0.f;
+    for (int k = 0; k < 3; ++k) g_p[k] = dd[k] / ne - m.v[k] * c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// F4-F8, F10, F13: projection of one Gaussian.  render.py:106-258, 307-315; utils.py:10-96,152-191.
+// ---------------------------------------------------------------------------------------------
+struct ProjMid {
+    float xc, yc, zc;             // camera-space centre
+    float sg;                     // sigmoid(opacity_raw)
+    float iz;                     // 1 / max(zc, 1e-6)
+    float j00, j11, j02, j12;     // Jacobian entries (render.py:165-171)
+    float C[6];                   // camera-space covariance (xx,xy,xz,yy,yz,zz)
+    float a, b, d;                // 2D covariance before the eigen clamp
+    float l1, l2, f1, f2, rad, diff;
+    bool clamped;
+    float a2, b2, d2;             // after the eigen clamp (render.py:177-179)
+    float det, sdet;              // utils.py:184-185
+    float i00, i11;               // inverse diagonal before the min_conis clamp
+};
+
+struct Proj {
+    float u, v, z;
+    float A11, A12, A22;          // conic
+    float opacity;
+    int tx0, ty0, tx1, ty1;       // inclusive tile rectangle
+    int vis;                      // VIS_*
+};
+
+GS_HD void project_gaussian(const float p[3], const float S[6], float o_raw, const Camera& cam, const ViewK& vk, Proj& o,
+                            ProjMid& m) {
+    o.vis = VIS_CULLED;
+    o.tx0 = o.ty0 = 0; o.tx1 = o.ty1 = -1;
+    // F4 opacity prefilter
+    m.sg = sigmoidf_(o_raw);
+    o.opacity = clampf_(m.sg, 0.f, 0.999f);
+    if (!(o.opacity >= vk.opacity_min)) return;
+    // F5 camera transform
+    const float* w = cam.w;
+    m.xc = w[0] * p[0] + w[1] * p[1] + w[2] * p[2] + cam.t[0];
+    m.yc = w[3] * p[0] + w[4] * p[1] + w[5] * p[2] + cam.t[1];
+    m.zc = w[6] * p[0] + w[7] * p[1] + w[8] * p[2] + cam.t[2];
+    o.z = m.zc;
+    // F6 frustum + guard band, strict inequalities
+    const float fxx = vk.fx * m.xc, fyy = vk.fy * m.yc;
+    const bool in = (m.zc > 0.f) && (m.zc > vk.near_z) && (m.zc < vk.far_z) && (fxx > m.zc * vk.gl) && (fxx < m.zc * vk.gr) &&
+                    (fyy > m.zc * vk.gt) && (fyy < m.zc * vk.gb);
+    if (!in) return;
+    // F7 projection and EWA covariance
+    o.u = fxx / m.zc + vk.cx;
+    o.v = fyy / m.zc + vk.cy;
+    // C = W S W^T
+    float M[9];
+    for (int i = 0; i < 3; ++i) {
+        const float w0 = w[i * 3 + 0], w1 = w[i * 3 + 1], w2 = w[i * 3 + 2];
+        M[i * 3 + 0] = w0 * S[0] + w1 * S[1] + w2 * S[2];
+        M[i * 3 + 1] = w0 * S[1] + w1 * S[3] + w2 * S[4];
+        M[i * 3 + 2] = w0 * S[2] + w1 * S[4] + w2 * S[5];
+    }
+    m.C[0] = M[0] * w[0] + M[1] * w[1] + M[2] * w[2];
+    m.C[1] = M[0] * w[3] + M[1] * w[4] + M[2] * w[5];
+    m.C[2] = M[0] * w[6] + M[1] * w[7] + M[2] * w[8];
+    m.C[3] = M[3] * w[3] + M[4] * w[4] + M[5] * w[5];
+    m.C[4] = M[3] * w[6] + M[4] * w[7] + M[5] * w[8];
+    m.C[5] = M[6] * w[6] + M[7] * w[7] + M[8] * w[8];
+    m.iz = 1.0f / fmaxf(m.zc, 1e-6f);
+    const float iz2 = m.iz * m.iz;
+    m.j00 = vk.fx * m.iz; m.j11 = vk.fy * m.iz;
+    m.j02 = -vk.fx * m.xc * iz2; m.j12 = -vk.fy * m.yc * iz2;
+    const float* C = m.C;
+    // rows of J*C
+    const float r0x = m.j00 * C[0] + m.j02 * C[2], r0y = m.j00 * C[1] + m.j02 * C[4], r0z = m.j00 * C[2] + m.j02 * C[5];
+    const float r1y = m.j11 * C[3] + m.j12 * C[4], r1z = m.j11 * C[4] + m.j12 * C[5];
+    m.a = r0x * m.j00 + r0z * m.j02;
+    m.b = r0y * m.j11 + r0z * m.j12;
+    m.d = r1y * m.j11 + r1z * m.j12;
+    // F8 eigenvalues of the symmetric 2x2, clamp to [1e-6, 1e4], recomposition
+    const float mid = 0.5f * (m.a + m.d);
+    m.diff = 0.5f * (m.a - m.d);
+    m.rad = sqrtf(m.diff * m.diff + m.b * m.b);
+    m.l1 = mid + m.rad; m.l2 = mid - m.rad;
+    m.f1 = clampf_(m.l1, 1e-6f, 1e4f); m.f2 = clampf_(m.l2, 1e-6f, 1e4f);
+    m.clamped = (m.f1 != m.l1) || (m.f2 != m.l2);
+    if (!m.clamped) {
+        m.a2 = m.a; m.b2 = m.b; m.d2 = m.d;
+    } else if (m.rad > 0.f) {
+        // f(S) = f2 I + k (S - l2 I), k = (f1 - f2) / (l1 - l2); (S - l2 I) computed without cancellation
+        const float k = (m.f1 - m.f2) / (2.f * m.rad);
+        float am, dm;   // a - l2, d - l2
+        if (m.diff > 0.f) { am = m.rad + m.diff; dm = (m.b * m.b) / am; }
+        else { dm = m.rad - m.diff; am = (m.b * m.b) / dm; }
+        m.a2 = m.f2 + k * am; m.d2 = m.f2 + k * dm; m.b2 = k * m.b;
+    } else {
+        m.a2 = m.f1; m.d2 = m.f1; m.b2 = 0.f;
+    }
+    if (!(isfinite(m.a2) && isfinite(m.b2) && isfinite(m.d2))) return;       // render.py:187-201
+    // F10 radius, AABB, on-screen test
+    const float lam = fminf(fmaxf(m.f1, 1e-12f), 1e4f);
+    const float r = ceilf(2.5f * sqrtf(lam));
+    const float umin = floorf(o.u - r), umax = floorf(o.u + r), vmin = floorf(o.v - r), vmax = floorf(o.v + r);
+    // F13 conic
+    m.det = m.a2 * m.d2 - m.b2 * m.b2;
+    m.sdet = fmaxf(m.det, 1e-12f);
+    m.i00 = m.d2 / m.sdet; m.i11 = m.a2 / m.sdet;
+    o.A11 = fmaxf(m.i00, vk.min_conis);
+    o.A12 = -m.b2 / m.sdet;
+    o.A22 = fmaxf(m.i11, vk.min_conis);
+    if (!(umax >= 0.f && umin < (float)vk.W && vmax >= 0.f && vmin < (float)vk.H)) { o.vis = VIS_OFFSCREEN; return; }
+    const float wm = (float)(vk.W - 1), hm = (float)(vk.H - 1);
+    o.tx0 = (int)clampf_(umin, 0.f, wm) / vk.tile;
+    o.tx1 = (int)clampf_(umax, 0.f, wm) / vk.tile;
+    o.ty0 = (int)clampf_(vmin, 0.f, hm) / vk.tile;
+    o.ty1 = (int)clampf_(vmax, 0.f, hm) / vk.tile;
+    o.vis = VIS_OK;
+}
+
+// B2.  Inputs: gradients w.r.t. (u, v, A11, A12, A22, opacity) of a VISIBLE Gaussian (its ProjMid recomputed by
+// project_gaussian).  Outputs: g_p[3] (position), G_S[9] (full symmetric world-covariance gradient), g_o_raw.
+GS_HD void project_gaussian_backward(const ProjMid& m, const Proj& o, const Camera& cam, const ViewK& vk, float g_u, float g_v,
+                                     float g_A11, float g_A12, float g_A22, float g_opacity, float g_p[3], float G_S[9],
+                                     float& g_o_raw) {
+    // opacity = clamp(sigmoid, 0, 0.999)
+    g_o_raw = (m.sg <= 0.999f) ? g_opacity * m.sg * (1.f - m.sg) : 0.f;
+    // min_conis clamp (render.py:310-311): gradient passes where the value is >= the bound
+    const float g00 = (m.i00 >= vk.min_conis) ? g_A11 : 0.f;
+    const float g11 = (m.i11 >= vk.min_conis) ? g_A22 : 0.f;
+    const float g01 = g_A12;
+    // inv2x2 with clamped determinant (utils.py:180-191); b and c of the reference are both b2 here
+    const float is = 1.0f / m.sdet;
+    float ga = g11 * is, gd = g00 * is, gb = -g01 * is, gc = 0.f;
+    const float gsdet = -(g00 * m.d2 - g01 * m.b2 + g11 * m.a2) * is * is;
+    const float gdet = (m.det >= 1e-12f) ? gsdet : 0.f;
+    ga += m.d2 * gdet; gd += m.a2 * gdet; gb += -m.b2 * gdet; gc += -m.b2 * gdet;
+    float Ga = ga, Gb = 0.5f * (gb + gc), Gd = gd;            // symmetrised 2x2 gradient w.r.t. the clamped covariance
+    if (m.clamped) {
+        // Daleckii-Krein: G = V [(V^T Gs V) o K] V^T, K_ii = f'(l_i), K_12 = (f1-f2)/(l1-l2)
+        float cx_, sx_;
+        if (m.rad > 0.f) {
+            float ex, ey;
+            if (m.diff > 0.f) { ex = m.rad + m.diff; ey = m.b; } else { ex = m.b; ey = m.rad - m.diff; }
+            const float inv = 1.0f / sqrtf(ex * ex + ey * ey);
+            cx_ = ex * inv; sx_ = ey * inv;
+        } else { cx_ = 1.f; sx_ = 0.f; }
+        const float k11 = (m.l1 >= 1e-6f && m.l1 <= 1e4f) ? 1.f : 0.f;
+        const float k22 = (m.l2 >= 1e-6f && m.l2 <= 1e4f) ? 1.f : 0.f;
+        const float k12 = (m.rad > 0.f) ? (m.f1 - m.f2) / (2.f * m.rad) : k11;
+        // v1 = (c, s), v2 = (-s, c)
+        const float t11 = cx_ * (Ga * cx_ + Gb * sx_) + sx_ * (Gb * cx_ + Gd * sx_);
+        const float t12 = cx_ * (-Ga * sx_ + Gb * cx_) + sx_ * (-Gb * sx_ + Gd * cx_);
+        const float t22 = -sx_ * (-Ga * sx_ + Gb * cx_) + cx_ * (-Gb * sx_ + Gd * cx_);
+        const float h11 = k11 * t11, h12 = k12 * t12, h22 = k22 * t22;
+        Ga = h11 * cx_ * cx_ - 2.f * h12 * cx_ * sx_ + h22 * sx_ * sx_;
+        Gb = h11 * cx_ * sx_ + h12 * (cx_ * cx_ - sx_ * sx_) - h22 * cx_ * sx_;
+        Gd = h11 * sx_ * sx_ + 2.f * h12 * cx_ * sx_ + h22 * cx_ * cx_;
+    }
+    // S2 = J C J^T :  dC = J^T G J,  dJ = 2 G J C
+    const float* C = m.C;
+    const float jc0x = m.j00 * C[0] + m.j02 * C[2], jc0y = m.j00 * C[1] + m.j02 * C[4], jc0z = m.j00 * C[2] + m.j02 * C[5];
+    const float jc1x = m.j11 * C[1] + m.j12 * C[2], jc1y = m.j11 * C[3] + m.j12 * C[4], jc1z = m.j11 * C[4] + m.j12 * C[5];
+    const float dJ00 = 2.f * (Ga * jc0x + Gb * jc1x);
+    const float dJ02 = 2.f * (Ga * jc0z + Gb * jc1z);
+    const float dJ11 = 2.f * (Gb * jc0y + Gd * jc1y);
+    const float dJ12 = 2.f * (Gb * jc0z + Gd * jc1z);
+    // J^T G J with J = [[j00,0,j02],[0,j11,j12]]
+    float dC[9];
+    const float gj0x = Ga * m.j00, gj0y = Gb * m.j11, gj0z = Ga * m.j02 + Gb * m.j12;   // row 0 of G J
+    const float gj1x = Gb * m.j00, gj1y = Gd * m.j11, gj1z = Gb * m.j02 + Gd * m.j12;   // row 1 of G J
+    dC[0] = m.j00 * gj0x; dC[1] = m.j00 * gj0y; dC[2] = m.j00 * gj0z;
+    dC[3] = m.j11 * gj1x; dC[4] = m.j11 * gj1y; dC[5] = m.j11 * gj1z;
+    dC[6] = m.j02 * gj0x + m.j12 * gj1x; dC[7] = m.j02 * gj0y + m.j12 * gj1y; dC[8] = m.j02 * gj0z + m.j12 * gj1z;
+    // dS = W^T dC W
+    const float* w = cam.w;
+    float T[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) T[i * 3 + j] = dC[i * 3 + 0] * w[0 + j] + dC[i * 3 + 1] * w[3 + j] + dC[i * 3 + 2] * w[6 + j];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) G_S[i * 3 + j] = w[0 + i] * T[0 + j] + w[3 + i] * T[3 + j] + w[6 + i] * T[6 + j];
+    // camera-space point
+    const float iz2 = m.iz * m.iz;
+    float dxc = -vk.fx * iz2 * dJ02;
+    float dyc = -vk.fy * iz2 * dJ12;
+    const float diz = vk.fx * dJ00 + vk.fy * dJ11 - 2.f * vk.fx * m.xc * m.iz * dJ02 - 2.f * vk.fy * m.yc * m.iz * dJ12;
+    float dzc = (m.zc >= 1e-6f) ? -iz2 * diz : 0.f;
+    const float rz = 1.0f / m.zc;
+    dxc += vk.fx * rz * g_u; dzc += -vk.fx * m.xc * rz * rz * g_u;
+    dyc += vk.fy * rz * g_v; dzc += -vk.fy * m.yc * rz * rz * g_v;
+    g_p[0] = w[0] * dxc + w[3] * dyc + w[6] * dzc;
+    g_p[1] = w[1] * dxc + w[4] * dyc + w[7] * dzc;
+    g_p[2] = w[2] * dxc + w[5] * dyc + w[8] * dzc;
+    (void)o;
+}
+
+}  // namespace gsm

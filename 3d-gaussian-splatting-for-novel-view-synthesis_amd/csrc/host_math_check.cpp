@@ -1,0 +1,51 @@
+// host_math_check.cpp -- host build of the per-Gaussian bodies in gs_body.h, for CPU unit tests only.
+//
+// NOT part of the product path: the product library (libgsplat_mi355x.so) contains only HIP kernels and fails
+// loudly without a GPU.  This file lets `pytest -m "not gpu"` check the projection math (forward and analytic
+// backward) against the oracle on a machine with no GPU, before any GPU time is spent.
+#include "gs_body.h"
+
+using namespace gsm;
+
+extern "C" {
+
+void hm_project(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, float* rec0, float* rec1, float* rec2,
+                uint32_t* tiles, int32_t* vis) {
+    Camera cam; build_camera(c2w, cam);
+    const ViewK vk = make_viewk(*v);
+    const bool fused = g->scale_raw != nullptr;
+    Records out{(f4*)rec0, (f4*)rec1, (f4*)rec2, tiles};
+    for (int64_t i = 0; i < g->n; ++i) {
+        ShCoefGlobal coef{fused ? g->f_dc + i * 3 : nullptr, fused ? g->f_rest + i * 45 : nullptr};
+        vis[i] = project_one(i, *g, fused, coef, cam, vk, out);
+    }
+}
+
+void hm_project_backward(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, const uint32_t* tiles,
+                         const float* grad2d, const gsplat_gaussian_grads* out) {
+    Camera cam; build_camera(c2w, cam);
+    const ViewK vk = make_viewk(*v);
+    const bool fused = g->scale_raw != nullptr;
+    for (int64_t i = 0; i < g->n; ++i) {
+        ShCoefGlobal coef{fused ? g->f_dc + i * 3 : nullptr, fused ? g->f_rest + i * 45 : nullptr};
+        ShEmitGlobal emit{fused ? out->f_dc + i * 3 : nullptr, fused ? out->f_rest + i * 45 : nullptr};
+        project_backward_one(i, *g, fused, coef, emit, cam, vk, tiles, grad2d, *out);
+    }
+}
+
+void hm_build_sigma(int64_t n, const float* scale_raw, const float* q_raw, float* sigma) {
+    for (int64_t i = 0; i < n; ++i) build_sigma_one(i, scale_raw, q_raw, sigma);
+}
+void hm_build_sigma_backward(int64_t n, const float* scale_raw, const float* q_raw, const float* grad_sigma, float* gs, float* gq) {
+    for (int64_t i = 0; i < n; ++i) build_sigma_backward_one(i, scale_raw, q_raw, grad_sigma, gs, gq);
+}
+void hm_evaluate_sh(int64_t n, const float* f_dc, const float* f_rest, const float* pts, const float* c2w, float* color) {
+    Camera cam; build_camera(c2w, cam);
+    for (int64_t i = 0; i < n; ++i) evaluate_sh_one(i, f_dc, f_rest, pts, cam, color);
+}
+void hm_evaluate_sh_backward(int64_t n, const float* f_dc, const float* f_rest, const float* pts, const float* c2w,
+                             const float* grad_color, float* g_dc, float* g_rest, float* g_pts) {
+    Camera cam; build_camera(c2w, cam);
+    for (int64_t i = 0; i < n; ++i) evaluate_sh_backward_one(i, f_dc, f_rest, pts, cam, grad_color, g_dc, g_rest, g_pts);
+}
+}

@@ -1,0 +1,158 @@
+/*
+ * gsplat_mi355x.h -- C ABI of the MI355X-native differentiable Gaussian-splat rasterizer.
+ *
+ * Drop-in boundary for the hot path of ashu1069/3D-Gaussian-Splatting-for-Novel-View-Synthesis.
+ * The reference has no FFI of its own: its boundary is three Python functions in the
+ * `gaussian_splatting` namespace (reference gaussian_splatting/__init__.py:7-21).  This header is
+ * what a binding for those three functions links against; INTEGRATION.md shows the ctypes stub.
+ *
+ *   reference function (file:line)                               replaced by
+ *   ------------------------------------------------------------ --------------------------------------
+ *   render()                  gaussian_splatting/render.py:62    gsplat_project + gsplat_bin +
+ *                                                                gsplat_rasterize_forward (+ the two
+ *                                                                *_backward calls for autograd)
+ *   build_sigma_from_params() gaussian_splatting/gaussian.py:71  gsplat_build_sigma[_backward], or folded
+ *                                                                into gsplat_project (fused inputs)
+ *   evaluate_sh()   gaussian_splatting/spherical_harmonics.py:70 gsplat_evaluate_sh[_backward], or folded
+ *                                                                into gsplat_project (fused inputs)
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in any signature; `stream` is a hipStream_t passed as void*.
+ *   - every pointer is a DEVICE pointer to fp32 data in the reference's own tensor layout
+ *     (pos[N,3], f_rest[N,45] channel-major, sigma[N,3,3], image[H,W,3] ...), except where a
+ *     parameter name ends in `_host`.
+ *   - the library never allocates or frees memory the caller can see: inputs, outputs, state kept
+ *     for the backward pass and scratch are caller-owned (PyTorch tensors in the Python host).
+ *     `*_bytes()` functions give the sizes; the internal carving is private to the library.
+ *   - every call is stream-ordered and returns immediately (no host synchronisation inside).
+ *   - return value: GSPLAT_OK or a GSPLAT_ERR_* code; gsplat_last_error() gives the text
+ *     (thread-local).
+ */
+#ifndef GSPLAT_MI355X_H
+#define GSPLAT_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSPLAT_ABI_VERSION 1
+
+/* call status */
+#define GSPLAT_OK 0
+#define GSPLAT_ERR_BAD_ARG 1     /* null pointer, negative size, unsupported tile size ...          */
+#define GSPLAT_ERR_HIP 2         /* a HIP runtime call or kernel launch failed                      */
+#define GSPLAT_ERR_WORKSPACE 3   /* caller-provided state / scratch buffer too small                */
+
+/* scene status, from gsplat_classify_counts(): mirrors the reference's empty / error conventions   */
+#define GSPLAT_SCENE_OK 0
+#define GSPLAT_SCENE_ALL_CULLED 10     /* render.py:109-112,139-142,182-193,206-209 -> zero image   */
+#define GSPLAT_SCENE_ALL_OFFSCREEN 11  /* render.py:235-236 -> Exception("All projected points ...") */
+
+/* Per-view scalars: the intrinsics and the 8 keyword arguments of render() (render.py:62-64).      */
+typedef struct gsplat_view {
+    int32_t H, W;                 /* image size                                                      */
+    float fx, fy, cx, cy;         /* pinhole intrinsics (pixels)                                     */
+    float near_z, far_z;          /* near=0.01, far=100.0                                            */
+    float pix_guard;              /* 32                                                              */
+    int32_t tile;                 /* T=16 (the only tile size the HIP kernels are built for)         */
+    float min_conis;              /* 1e-6                                                            */
+    float chi_square_clip;        /* 6.25                                                            */
+    float alpha_max;              /* 0.99                                                            */
+    float alpha_cutoff;           /* 1/128                                                           */
+} gsplat_view;
+
+/* Gaussian parameters of one scene.  Exactly one of the two input sets is given:
+ *   un-fused (the reference render() signature): color + sigma, the four fused pointers NULL;
+ *   fused (build_sigma_from_params + evaluate_sh folded in): scale_raw, q_raw, f_dc, f_rest,
+ *          color and sigma NULL.                                                                    */
+typedef struct gsplat_gaussians {
+    int64_t n;
+    const float* pos;           /* [n,3]                                                             */
+    const float* opacity_raw;   /* [n]                                                               */
+    const float* color;         /* [n,3]   or NULL                                                   */
+    const float* sigma;         /* [n,3,3] or NULL                                                   */
+    const float* scale_raw;     /* [n,3]   or NULL   (log scale)                                     */
+    const float* q_raw;         /* [n,4]   or NULL   (x,y,z,w), un-normalised                        */
+    const float* f_dc;          /* [n,3]   or NULL                                                   */
+    const float* f_rest;        /* [n,45]  or NULL   channel-major R1..R15,G1..G15,B1..B15           */
+} gsplat_gaussians;
+
+/* Gradient outputs, same shapes as the inputs of gsplat_gaussians; unused ones NULL.
+ * Every row is written (rows of culled Gaussians get zeros, as in the reference).                    */
+typedef struct gsplat_gaussian_grads {
+    float* pos;
+    float* opacity_raw;
+    float* color;
+    float* sigma;
+    float* scale_raw;
+    float* q_raw;
+    float* f_dc;
+    float* f_rest;
+} gsplat_gaussian_grads;
+
+/* Counters produced by gsplat_project (copied to pinned host memory when asked).                    */
+typedef struct gsplat_counts {
+    int32_t n_survivors;   /* pass the opacity prefilter, frustum cull and finite check              */
+    int32_t n_visible;     /* ... and have an on-screen AABB  (V of SURVEY.md)                       */
+    int64_t n_pairs;       /* total (tile, Gaussian) pairs    (P of SURVEY.md)                       */
+    int32_t max_tiles_per_gaussian;
+    int32_t reserved;
+} gsplat_counts;
+
+int gsplat_abi_version(void);
+const char* gsplat_last_error(void);
+int gsplat_classify_counts(const gsplat_counts* counts_host);
+
+/* ---- buffer sizes (bytes) ---------------------------------------------------------------------- */
+int64_t gsplat_project_state_bytes(int64_t n);                         /* kept until the backward pass */
+int64_t gsplat_project_scratch_bytes(int64_t n);                       /* free after gsplat_project    */
+int64_t gsplat_bin_state_bytes(int64_t n_pairs, const gsplat_view* v); /* kept until the backward pass */
+int64_t gsplat_bin_scratch_bytes(int64_t n, int64_t n_pairs);          /* free after gsplat_bin        */
+
+/* ---- forward ----------------------------------------------------------------------------------- */
+/* F1-F8, F10, F13 (+F2, F3 when fused): per-Gaussian projection, culls, EWA covariance, eigen clamp,
+ * conic, tile rectangle, colour; then the prefix sum of tiles-per-Gaussian.  c2w is the DEVICE
+ * [4,4] row-major camera-to-world matrix (no host read -> no synchronisation).  If counts_host is
+ * not NULL the counters are copied there with hipMemcpyAsync on `stream`; the caller synchronises
+ * the stream before reading them (it needs n_pairs to size the gsplat_bin buffers).                   */
+int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, void* project_state,
+                   void* scratch, int64_t scratch_bytes, gsplat_counts* counts_host, void* stream);
+
+/* F9, F11, F12: (tile, depth) keyed pair list, sorted; per-tile [start, end).  Order inside a tile is
+ * (camera depth, Gaussian index) ascending.                                                           */
+int gsplat_bin(int64_t n, int64_t n_pairs, const gsplat_view* v, const void* project_state, void* bin_state,
+               void* scratch, int64_t scratch_bytes, void* stream);
+
+/* F14, F15: per-tile front-to-back compositing.  image[H,W,3] receives clamp(C,0,1); accum[H,W,3]
+ * (nullable; required for the backward pass) receives the unclamped C.                                */
+int gsplat_rasterize_forward(int64_t n, int64_t n_pairs, const gsplat_view* v, const void* project_state,
+                             const void* bin_state, float* image, float* accum, void* stream);
+
+/* ---- backward ---------------------------------------------------------------------------------- */
+/* B1: gradient of the compositing w.r.t. the per-Gaussian 2D quantities.  grad2d is [n,16] floats
+ * (u, v, conic a, b, c, opacity, r, g, b, pad...) and is zeroed by this call before accumulation.     */
+int gsplat_rasterize_backward(int64_t n, int64_t n_pairs, const gsplat_view* v, const void* project_state,
+                              const void* bin_state, const float* accum, const float* grad_image,
+                              float* grad2d, void* stream);
+
+/* B2 (+B3 when fused): chain the 2D gradients back to the inputs of gsplat_project.                   */
+int gsplat_project_backward(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v,
+                            const void* project_state, const float* grad2d, const gsplat_gaussian_grads* out,
+                            void* stream);
+
+/* ---- the two small exported functions as stand-alone ops --------------------------------------- */
+int gsplat_build_sigma(int64_t n, const float* scale_raw, const float* q_raw, float* sigma, void* stream);
+int gsplat_build_sigma_backward(int64_t n, const float* scale_raw, const float* q_raw, const float* grad_sigma,
+                                float* grad_scale_raw, float* grad_q_raw, void* stream);
+int gsplat_evaluate_sh(int64_t n, const float* f_dc, const float* f_rest, const float* points, const float* c2w,
+                       float* color, void* stream);
+int gsplat_evaluate_sh_backward(int64_t n, const float* f_dc, const float* f_rest, const float* points,
+                                const float* c2w, const float* grad_color, float* grad_f_dc, float* grad_f_rest,
+                                float* grad_points, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSPLAT_MI355X_H */
