@@ -1,1 +1,19 @@
-"""placeholder"""
+"""MI355X-native differentiable Gaussian-splat rasterizer: drop-in for the hot path of
+ashu1069/3D-Gaussian-Splatting-for-Novel-View-Synthesis (its `gaussian_splatting` namespace,
+reference gaussian_splatting/__init__.py:7-21).
+
+The directory name is not a Python identifier; import it with
+
+    import importlib
+    gs = importlib.import_module("3d-gaussian-splatting-for-novel-view-synthesis_amd")
+
+or through the alias module `gsplat_amd` at the repository root.  Same eight names as the reference namespace,
+plus the fused entry `render_gaussians` and the data-parallel helpers in `.dp`.
+"""
+from .ops import (HARMONICS, build_sigma_from_params, evaluate_sh, inv2x2, project_points, quat_to_rotmat, render,
+                  render_gaussians, render_stats, scale_intrinsics)
+
+__all__ = [
+    'build_sigma_from_params', 'quat_to_rotmat', 'evaluate_sh', 'HARMONICS', 'render', 'project_points', 'inv2x2',
+    'scale_intrinsics', 'render_gaussians', 'render_stats',
+]

@@ -1,0 +1,704 @@
+// gsplat_kernels.hip -- MI355X (gfx950, wave64) kernels and the C ABI of include/gsplat_mi355x.h.
+//
+// Pipeline (stage ids of SURVEY.md §8a in brackets):
+//   K0 camera_kernel            c2w (device) -> Camera block                         [F5 setup]
+//   K1 project_kernel           per Gaussian: culls, EWA, eigen clamp, conic, rect   [F1-F8, F10, F13]
+//   K2 rocprim inclusive_scan   tiles-per-Gaussian -> pair offsets                   [F11]
+//   K3 emit_pairs_kernel        (tile << 32 | depth bits, id) per covered tile       [F11]
+//   K4 rocprim radix_sort_pairs stable -> (tile, depth, id) order                    [F9, F12]
+//   K5 tile_ranges_kernel       per-tile [start, end)                                [F12]
+//   K6 raster_forward_kernel    one wave64 per 16x16 tile, 4 pixels per lane         [F14, F15]
+//   K7 raster_backward_kernel   same traversal, analytic gradients, wave reduction   [B1]
+//   K8 project_backward_kernel  chain rule to the reference's input tensors          [B2, B3]
+//
+// No MFMA: there is no dense contraction on this path.  No CPU fallback: without a GPU every entry
+// point returns GSPLAT_ERR_HIP.
+#include <cstdio>
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "gs_body.h"
+
+using namespace gsm;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, const char* a = "", const char* b = "") {
+    snprintf(g_err, sizeof(g_err), fmt, a, b);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) return fail(GSPLAT_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define LAUNCH_CHECK(name)                                                              \
+    do {                                                                                \
+        hipError_t e_ = hipGetLastError();                                              \
+        if (e_ != hipSuccess) return fail(GSPLAT_ERR_HIP, "launch %s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr int64_t ALIGN = 256;
+inline int64_t up(int64_t x) { return (x + ALIGN - 1) / ALIGN * ALIGN; }
+
+// ---- layout of the caller-owned buffers (private to the library) ---------------------------------
+struct DevCounts {           // device-side counters; copied into gsplat_counts
+    int32_t n_survivors, n_visible;
+    int64_t n_pairs;
+    int32_t max_tiles, reserved;
+};
+static_assert(sizeof(DevCounts) == sizeof(gsplat_counts), "counts layout");
+
+struct ProjectState {
+    Camera* cam;
+    DevCounts* counts;
+    f4 *rec0, *rec1, *rec2;
+    uint32_t* tiles;
+    uint32_t* offsets;       // inclusive prefix sum of tiles
+    int64_t bytes;
+};
+
+ProjectState carve_project(void* base, int64_t n) {
+    ProjectState s;
+    char* p = (char*)base;
+    int64_t o = 0;
+    s.cam = (Camera*)(p + o); o += up(sizeof(Camera));
+    s.counts = (DevCounts*)(p + o); o += up(sizeof(DevCounts));
+    s.rec0 = (f4*)(p + o); o += up(n * 16);
+    s.rec1 = (f4*)(p + o); o += up(n * 16);
+    s.rec2 = (f4*)(p + o); o += up(n * 16);
+    s.tiles = (uint32_t*)(p + o); o += up(n * 4);
+    s.offsets = (uint32_t*)(p + o); o += up(n * 4);
+    s.bytes = o;
+    return s;
+}
+
+struct BinState {
+    uint32_t* sorted_ids;    // [P] Gaussian ids in (tile, depth, id) order
+    uint2* ranges;           // [tiles] start, end
+    int64_t bytes;
+};
+
+BinState carve_bin(void* base, int64_t n_pairs, int64_t n_tiles) {
+    BinState s;
+    char* p = (char*)base;
+    int64_t o = 0;
+    s.sorted_ids = (uint32_t*)(p + o); o += up((n_pairs > 0 ? n_pairs : 1) * 4);
+    s.ranges = (uint2*)(p + o); o += up(n_tiles * 8);
+    s.bytes = o;
+    return s;
+}
+
+struct BinScratch {
+    uint64_t *keys_in, *keys_out;
+    uint32_t* vals_in;
+    void* sort_temp;
+    size_t sort_temp_bytes;
+    int64_t bytes;
+};
+
+size_t sort_temp_bytes(int64_t n_pairs) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                              (size_t)(n_pairs > 0 ? n_pairs : 1), 0u, 64u, (hipStream_t)0);
+    return bytes;
+}
+
+BinScratch carve_bin_scratch(void* base, int64_t n_pairs) {
+    BinScratch s;
+    char* p = (char*)base;
+    int64_t o = 0;
+    const int64_t np = n_pairs > 0 ? n_pairs : 1;
+    s.keys_in = (uint64_t*)(p + o); o += up(np * 8);
+    s.keys_out = (uint64_t*)(p + o); o += up(np * 8);
+    s.vals_in = (uint32_t*)(p + o); o += up(np * 4);
+    s.sort_temp_bytes = sort_temp_bytes(np);
+    s.sort_temp = (void*)(p + o); o += up((int64_t)s.sort_temp_bytes);
+    s.bytes = o;
+    return s;
+}
+
+size_t scan_temp_bytes(int64_t n) {
+    size_t bytes = 0;
+    (void)rocprim::inclusive_scan(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)(n > 0 ? n : 1),
+                            rocprim::plus<uint32_t>(), (hipStream_t)0);
+    return bytes;
+}
+
+int check_view(const gsplat_view* v) {
+    if (!v) return fail(GSPLAT_ERR_BAD_ARG, "view is NULL");
+    if (v->H <= 0 || v->W <= 0) return fail(GSPLAT_ERR_BAD_ARG, "image size must be positive");
+    if (v->tile != 16) return fail(GSPLAT_ERR_BAD_ARG, "only tile size T=16 is built (the image does not depend on T)");
+    if ((v->W + 15) / 16 > 65535 || (v->H + 15) / 16 > 65535) return fail(GSPLAT_ERR_BAD_ARG, "image too large");
+    return GSPLAT_OK;
+}
+
+int check_gaussians(const gsplat_gaussians* g, bool* fused) {
+    if (!g) return fail(GSPLAT_ERR_BAD_ARG, "gaussians is NULL");
+    if (g->n < 0 || g->n > 0x7fffffffLL) return fail(GSPLAT_ERR_BAD_ARG, "n out of range");
+    const bool f = g->scale_raw || g->q_raw || g->f_dc || g->f_rest;
+    const bool u = g->color || g->sigma;
+    if (f == u) return fail(GSPLAT_ERR_BAD_ARG, "give either (color, sigma) or (scale_raw, q_raw, f_dc, f_rest)");
+    if (g->n > 0) {
+        if (!g->pos || !g->opacity_raw) return fail(GSPLAT_ERR_BAD_ARG, "pos / opacity_raw is NULL");
+        if (f && !(g->scale_raw && g->q_raw && g->f_dc && g->f_rest)) return fail(GSPLAT_ERR_BAD_ARG, "fused inputs incomplete");
+        if (u && !(g->color && g->sigma)) return fail(GSPLAT_ERR_BAD_ARG, "color / sigma is NULL");
+    }
+    *fused = f;
+    return GSPLAT_OK;
+}
+
+// ---- device helpers ------------------------------------------------------------------------------
+
+__device__ __forceinline__ float dpp_row_sum(float v) {
+    // sum across the 64 lanes with DPP; the total ends up in lane 63 (row 3)
+    int x;
+#define DPP_ADD(ctrl, rmask)                                                                       \
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xF, false);               \
+    v += __int_as_float(x);
+    DPP_ADD(0xB1, 0xF)    // quad_perm [1,0,3,2]
+    DPP_ADD(0x4E, 0xF)    // quad_perm [2,3,0,1]
+    DPP_ADD(0x141, 0xF)   // row_half_mirror
+    DPP_ADD(0x140, 0xF)   // row_mirror
+    DPP_ADD(0x142, 0xA)   // row_bcast15 -> rows 1, 3
+    DPP_ADD(0x143, 0xC)   // row_bcast31 -> rows 2, 3
+#undef DPP_ADD
+    return v;
+}
+
+__device__ __forceinline__ float wave_total(float v) {
+    v = dpp_row_sum(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// XCD-aware block -> tile map: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch), so give each
+// XCD group one contiguous range of tile ids (contiguous tile rows => neighbouring tiles => shared L2 lines).
+// Bijective for any tile count (cdna_hip_programming.md, "XCD swizzle must be bijective").
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t n) {
+    const uint32_t xcd = b & 7u, q = n >> 3, r = n & 7u;
+    const uint32_t start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + (b >> 3);
+}
+
+// ---- K0 ------------------------------------------------------------------------------------------
+__global__ void camera_kernel(const float* __restrict__ c2w, Camera* cam, DevCounts* counts) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float m[16];
+        for (int i = 0; i < 16; ++i) m[i] = c2w[i];
+        Camera c;
+        build_camera(m, c);
+        *cam = c;
+        counts->n_survivors = 0; counts->n_visible = 0; counts->n_pairs = 0; counts->max_tiles = 0; counts->reserved = 0;
+    }
+}
+
+// ---- K1 ------------------------------------------------------------------------------------------
+template <bool FUSED>
+__global__ __launch_bounds__(256) void project_kernel(gsplat_gaussians g, const Camera* __restrict__ camp, ViewK vk, Records out,
+                                                      DevCounts* counts) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const Camera cam = *camp;
+    int vis = VIS_CULLED;
+    uint32_t nt = 0;
+    if (i < g.n) {
+        ShCoefGlobal coef{FUSED ? g.f_dc + i * 3 : nullptr, FUSED ? g.f_rest + i * 45 : nullptr};
+        vis = project_one(i, g, FUSED, coef, cam, vk, out);
+        nt = out.tiles[i];
+    }
+    const unsigned long long surv = __ballot(vis != VIS_CULLED);
+    const unsigned long long seen = __ballot(vis == VIS_OK);
+    // wave max of tiles-per-Gaussian via DPP-free shuffle (rare path, tiny cost)
+    uint32_t mx = nt;
+    for (int s = 32; s > 0; s >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, s));
+    if ((threadIdx.x & 63) == 0) {
+        if (surv) atomicAdd(&counts->n_survivors, (int)__popcll(surv));
+        if (seen) atomicAdd(&counts->n_visible, (int)__popcll(seen));
+        if (mx) atomicMax(&counts->max_tiles, (int)mx);
+    }
+}
+
+__global__ void finish_counts_kernel(const uint32_t* __restrict__ offsets, int64_t n, DevCounts* counts) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) counts->n_pairs = n > 0 ? (int64_t)offsets[n - 1] : 0;
+}
+
+// ---- K3 ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void emit_pairs_kernel(int64_t n, const f4* __restrict__ rec2, const uint32_t* __restrict__ tiles,
+                                                         const uint32_t* __restrict__ offsets, int tiles_x, int64_t n_pairs,
+                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t nt = tiles[i];
+    if (nt == 0) return;
+    const f4 r = rec2[i];
+    const uint32_t lo = f2u(r.z), hi = f2u(r.w);
+    const int tx0 = lo & 0xFFFF, ty0 = lo >> 16, tx1 = hi & 0xFFFF, ty1 = hi >> 16;
+    const uint64_t zbits = f2u(r.y);              // z > 0: the bit pattern orders like the value
+    int64_t o = (int64_t)offsets[i] - nt;
+    for (int ty = ty0; ty <= ty1; ++ty)
+        for (int tx = tx0; tx <= tx1; ++tx) {
+            if (o < n_pairs) {                     // defensive: never write past the caller's buffer
+                keys[o] = ((uint64_t)(uint32_t)(ty * tiles_x + tx) << 32) | zbits;
+                vals[o] = (uint32_t)i;
+            }
+            ++o;
+        }
+}
+
+// ---- K5 ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t n_pairs, const uint64_t* __restrict__ keys, uint2* ranges) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pairs) return;
+    const uint32_t t = (uint32_t)(keys[i] >> 32);
+    if (i == 0 || (uint32_t)(keys[i - 1] >> 32) != t) ranges[t].x = (uint32_t)i;
+    if (i == n_pairs - 1 || (uint32_t)(keys[i + 1] >> 32) != t) ranges[t].y = (uint32_t)(i + 1);
+}
+
+// ---- K6 ------------------------------------------------------------------------------------------
+// One wave64 per 16x16 tile.  Lane l owns column (l & 15) and rows (l >> 4) + 4k, k = 0..3.  The tile's
+// Gaussian list is staged through LDS 64 records at a time (SoA, broadcast reads, conflict-free).
+constexpr int BATCH = 64;
+
+struct TileBatch {
+    float u[BATCH], v[BATCH], a[BATCH], b2[BATCH], c[BATCH], o[BATCH], r[BATCH], g[BATCH], bl[BATCH];
+};
+
+__device__ __forceinline__ void stage_batch(TileBatch& s, int lane, int n, const uint32_t* __restrict__ ids, uint32_t base,
+                                            const f4* __restrict__ rec0, const f4* __restrict__ rec1, const f4* __restrict__ rec2,
+                                            uint32_t* s_id) {
+    if (lane < n) {
+        const uint32_t id = ids[base + lane];
+        const f4 q0 = rec0[id], q1 = rec1[id];
+        const float bl = rec2[id].x;
+        s.u[lane] = q0.x; s.v[lane] = q0.y; s.a[lane] = q0.z; s.b2[lane] = 2.0f * q0.w;
+        s.c[lane] = q1.x; s.o[lane] = q1.y; s.r[lane] = q1.z; s.g[lane] = q1.w; s.bl[lane] = bl;
+        if (s_id) s_id[lane] = id;
+    }
+}
+
+__global__ __launch_bounds__(64) void raster_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ ids,
+                                                            const f4* __restrict__ rec0, const f4* __restrict__ rec1,
+                                                            const f4* __restrict__ rec2, int n_tiles, int tiles_x, int H, int W,
+                                                            float chi, float alpha_max, float alpha_cutoff,
+                                                            float* __restrict__ image, float* __restrict__ accum) {
+    __shared__ TileBatch s;
+    const int lane = threadIdx.x;
+    const uint32_t tile = xcd_tile(blockIdx.x, (uint32_t)n_tiles);
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int px = tx * 16 + (lane & 15);
+    const int py0 = ty * 16 + (lane >> 4);
+    const float fpx = (float)px;
+    float T[4], C[4][3], fpy[4];
+    bool valid[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int py = py0 + 4 * k;
+        valid[k] = (px < W) && (py < H);
+        fpy[k] = (float)py;
+        T[k] = valid[k] ? 1.0f : 0.0f;
+        C[k][0] = C[k][1] = C[k][2] = 0.f;
+    }
+    const uint2 rg = ranges[tile];
+    bool all_done = false;
+    for (uint32_t base = rg.x; base < rg.y && !all_done; base += BATCH) {
+        const int n = min((uint32_t)BATCH, rg.y - base);
+        __syncthreads();
+        stage_batch(s, lane, n, ids, base, rec0, rec1, rec2, nullptr);
+        __syncthreads();
+        for (int j = 0; j < n; ++j) {
+            const float du = fpx - s.u[j];
+            const float gv = s.v[j], ga = s.a[j], gb2 = s.b2[j], gc = s.c[j];
+            const float c0 = ga * du * du, c1 = gb2 * du;
+            float q[4];
+            bool any_in = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dv = fpy[k] - gv;
+                q[k] = c0 + dv * (c1 + gc * dv);
+                any_in |= (q[k] <= chi);
+            }
+            if (!__any(any_in)) continue;
+            const float go = s.o[j], cr = s.r[j], cg = s.g[j], cb = s.bl[j];
+            bool done = true;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gval = (q[k] <= chi) ? __expf(-0.5f * q[k]) : 0.0f;
+                float al = fminf(go * gval, alpha_max);
+                al = (al >= alpha_cutoff) ? al : 0.0f;
+                const bool alive = T[k] > 5e-5f;
+                const float w = alive ? al * T[k] : 0.0f;
+                C[k][0] += w * cr; C[k][1] += w * cg; C[k][2] += w * cb;
+                T[k] *= (1.0f - al);
+                done &= !(T[k] > 5e-5f);
+            }
+            if (__all(done)) { all_done = true; break; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (valid[k]) {
+            const int64_t o = ((int64_t)(py0 + 4 * k) * W + px) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                image[o + c] = fminf(fmaxf(C[k][c], 0.0f), 1.0f);
+                if (accum) accum[o + c] = C[k][c];
+            }
+        }
+    }
+}
+
+// ---- K7 ------------------------------------------------------------------------------------------
+// Same front-to-back traversal as K6 (identical T_i and alive decisions).  For pixel p and Gaussian i:
+//   d alpha_i = alive_i T_i (c_i . Gc) - (sum_{k>i} w_k (c_k . Gc)) / (1 - alpha_i),
+// the suffix sum being (total - running prefix), total = Gc . C_unclamped.  Nine per-Gaussian sums are reduced
+// over the wave with DPP and added to grad2d[id][0..8] by lanes 0..8 (one 36-byte atomic request per pair).
+__global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ ids,
+                                                             const f4* __restrict__ rec0, const f4* __restrict__ rec1,
+                                                             const f4* __restrict__ rec2, int n_tiles, int tiles_x, int H, int W,
+                                                             float chi, float alpha_max, float alpha_cutoff,
+                                                             const float* __restrict__ accum, const float* __restrict__ gimg,
+                                                             float* __restrict__ grad2d) {
+    __shared__ TileBatch s;
+    __shared__ uint32_t s_id[BATCH];
+    const int lane = threadIdx.x;
+    const uint32_t tile = xcd_tile(blockIdx.x, (uint32_t)n_tiles);
+    const uint2 rg = ranges[tile];
+    if (rg.x >= rg.y) return;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int px = tx * 16 + (lane & 15);
+    const int py0 = ty * 16 + (lane >> 4);
+    const float fpx = (float)px;
+    float T[4], fpy[4], G[4][3], suffix[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int py = py0 + 4 * k;
+        const bool valid = (px < W) && (py < H);
+        fpy[k] = (float)py;
+        T[k] = valid ? 1.0f : 0.0f;
+        suffix[k] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) G[k][c] = 0.f;
+        if (valid) {
+            const int64_t o = ((int64_t)py * W + px) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float cu = accum[o + c];
+                // clamp(C, 0, 1) passes the gradient where 0 <= C <= 1 (render.py:410)
+                const float gv = (cu >= 0.0f && cu <= 1.0f) ? gimg[o + c] : 0.0f;
+                G[k][c] = gv;
+                suffix[k] += gv * cu;
+            }
+        }
+    }
+    bool all_done = false;
+    for (uint32_t base = rg.x; base < rg.y && !all_done; base += BATCH) {
+        const int n = min((uint32_t)BATCH, rg.y - base);
+        __syncthreads();
+        stage_batch(s, lane, n, ids, base, rec0, rec1, rec2, s_id);
+        __syncthreads();
+        for (int j = 0; j < n; ++j) {
+            const float du = fpx - s.u[j];
+            const float gv = s.v[j], ga = s.a[j], gb2 = s.b2[j], gc = s.c[j];
+            const float c0 = ga * du * du, c1 = gb2 * du;
+            float q[4], dv[4];
+            bool any_in = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                dv[k] = fpy[k] - gv;
+                q[k] = c0 + dv[k] * (c1 + gc * dv[k]);
+                any_in |= (q[k] <= chi);
+            }
+            if (!__any(any_in)) continue;
+            const float go = s.o[j], cr = s.r[j], cg = s.g[j], cb = s.bl[j];
+            float a_u = 0.f, a_v = 0.f, a_A11 = 0.f, a_A12 = 0.f, a_A22 = 0.f, a_o = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f;
+            bool done = true, touched = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gval = (q[k] <= chi) ? __expf(-0.5f * q[k]) : 0.0f;
+                const float og = go * gval;
+                float al = fminf(og, alpha_max);
+                al = (al >= alpha_cutoff) ? al : 0.0f;
+                const bool alive = T[k] > 5e-5f;
+                if (alive && al > 0.0f) {
+                    touched = true;
+                    const float w = al * T[k];
+                    const float sdot = cr * G[k][0] + cg * G[k][1] + cb * G[k][2];
+                    a_r += w * G[k][0]; a_g += w * G[k][1]; a_b += w * G[k][2];
+                    suffix[k] -= w * sdot;                                   // now sum over k > i
+                    const float dal = T[k] * sdot - suffix[k] / (1.0f - al);
+                    if (og <= alpha_max) {                                   // clamp_max passes the gradient (render.py:372)
+                        a_o += dal * gval;
+                        const float dq = -0.5f * gval * go * dal;            // q <= chi here (gval > 0)
+                        const float du2 = du * dq, dv2 = dv[k] * dq;
+                        a_A11 += du * du2; a_A12 += 2.0f * du * dv2; a_A22 += dv[k] * dv2;
+                        a_u -= (2.0f * ga * du + gb2 * dv[k]) * dq;
+                        a_v -= (gb2 * du + 2.0f * gc * dv[k]) * dq;
+                    }
+                }
+                T[k] *= (1.0f - al);
+                done &= !(T[k] > 5e-5f);
+            }
+            if (__any(touched)) {
+                const float t0 = wave_total(a_u), t1 = wave_total(a_v), t2 = wave_total(a_A11), t3 = wave_total(a_A12),
+                            t4 = wave_total(a_A22), t5 = wave_total(a_o), t6 = wave_total(a_r), t7 = wave_total(a_g),
+                            t8 = wave_total(a_b);
+                if (lane < 9) {
+                    float mine = t0;
+                    mine = lane == 1 ? t1 : mine; mine = lane == 2 ? t2 : mine; mine = lane == 3 ? t3 : mine;
+                    mine = lane == 4 ? t4 : mine; mine = lane == 5 ? t5 : mine; mine = lane == 6 ? t6 : mine;
+                    mine = lane == 7 ? t7 : mine; mine = lane == 8 ? t8 : mine;
+                    atomicAdd(&grad2d[(int64_t)s_id[j] * 16 + lane], mine);
+                }
+            }
+            if (__all(done)) { all_done = true; break; }
+        }
+    }
+}
+
+// ---- K8 ------------------------------------------------------------------------------------------
+template <bool FUSED>
+__global__ __launch_bounds__(256) void project_backward_kernel(gsplat_gaussians g, const Camera* __restrict__ camp, ViewK vk,
+                                                               const uint32_t* __restrict__ tiles, const float* __restrict__ grad2d,
+                                                               gsplat_gaussian_grads out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.n) return;
+    const Camera cam = *camp;
+    ShCoefGlobal coef{FUSED ? g.f_dc + i * 3 : nullptr, FUSED ? g.f_rest + i * 45 : nullptr};
+    ShEmitGlobal emit{FUSED ? out.f_dc + i * 3 : nullptr, FUSED ? out.f_rest + i * 45 : nullptr};
+    project_backward_one(i, g, FUSED, coef, emit, cam, vk, tiles, grad2d, out);
+}
+
+// ---- stand-alone ops -------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void build_sigma_kernel(int64_t n, const float* __restrict__ sr, const float* __restrict__ qr,
+                                                          float* __restrict__ sigma) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) build_sigma_one(i, sr, qr, sigma);
+}
+__global__ __launch_bounds__(256) void build_sigma_backward_kernel(int64_t n, const float* __restrict__ sr, const float* __restrict__ qr,
+                                                                   const float* __restrict__ gs, float* __restrict__ gsr,
+                                                                   float* __restrict__ gq) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) build_sigma_backward_one(i, sr, qr, gs, gsr, gq);
+}
+__global__ __launch_bounds__(256) void evaluate_sh_kernel(int64_t n, const float* __restrict__ dc, const float* __restrict__ rest,
+                                                          const float* __restrict__ pts, const float* __restrict__ c2w,
+                                                          float* __restrict__ color) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float m[16];
+    for (int k = 0; k < 16; ++k) m[k] = c2w[k];
+    Camera cam;
+    build_camera(m, cam);
+    evaluate_sh_one(i, dc, rest, pts, cam, color);
+}
+__global__ __launch_bounds__(256) void evaluate_sh_backward_kernel(int64_t n, const float* __restrict__ dc, const float* __restrict__ rest,
+                                                                   const float* __restrict__ pts, const float* __restrict__ c2w,
+                                                                   const float* __restrict__ gcol, float* __restrict__ gdc,
+                                                                   float* __restrict__ grest, float* __restrict__ gpts) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float m[16];
+    for (int k = 0; k < 16; ++k) m[k] = c2w[k];
+    Camera cam;
+    build_camera(m, cam);
+    evaluate_sh_backward_one(i, dc, rest, pts, cam, gcol, gdc, grest, gpts);
+}
+
+inline unsigned blocks256(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+// ======================================================================================================
+// C ABI
+// ======================================================================================================
+extern "C" {
+
+int gsplat_abi_version(void) { return GSPLAT_ABI_VERSION; }
+
+const char* gsplat_last_error(void) { return g_err; }
+
+int gsplat_classify_counts(const gsplat_counts* c) {
+    if (!c) return GSPLAT_SCENE_ALL_CULLED;
+    if (c->n_survivors == 0) return GSPLAT_SCENE_ALL_CULLED;       // render.py:109-112,139-142,190-193
+    if (c->n_visible == 0) return GSPLAT_SCENE_ALL_OFFSCREEN;      // render.py:235-236
+    return GSPLAT_SCENE_OK;
+}
+
+int64_t gsplat_project_state_bytes(int64_t n) { return carve_project(nullptr, n > 0 ? n : 1).bytes; }
+
+int64_t gsplat_project_scratch_bytes(int64_t n) { return up((int64_t)scan_temp_bytes(n)) + ALIGN; }
+
+int64_t gsplat_bin_state_bytes(int64_t n_pairs, const gsplat_view* v) {
+    if (!v) return -1;
+    const int64_t nt = (int64_t)((v->W + 15) / 16) * ((v->H + 15) / 16);
+    return carve_bin(nullptr, n_pairs, nt).bytes;
+}
+
+int64_t gsplat_bin_scratch_bytes(int64_t n, int64_t n_pairs) {
+    (void)n;
+    return carve_bin_scratch(nullptr, n_pairs).bytes;
+}
+
+int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, void* project_state, void* scratch,
+                   int64_t scratch_bytes, gsplat_counts* counts_host, void* stream_) {
+    bool fused = false;
+    int rc = check_gaussians(g, &fused);
+    if (rc) return rc;
+    if ((rc = check_view(v))) return rc;
+    if (!c2w || !project_state) return fail(GSPLAT_ERR_BAD_ARG, "c2w / project_state is NULL");
+    hipStream_t st = (hipStream_t)stream_;
+    const int64_t n = g->n;
+    ProjectState ps = carve_project(project_state, n > 0 ? n : 1);
+    const ViewK vk = make_viewk(*v);
+    hipLaunchKernelGGL(camera_kernel, dim3(1), dim3(64), 0, st, c2w, ps.cam, ps.counts);
+    LAUNCH_CHECK("camera_kernel");
+    if (n > 0) {
+        Records out{ps.rec0, ps.rec1, ps.rec2, ps.tiles};
+        if (fused)
+            hipLaunchKernelGGL(project_kernel<true>, dim3(blocks256(n)), dim3(256), 0, st, *g, ps.cam, vk, out, ps.counts);
+        else
+            hipLaunchKernelGGL(project_kernel<false>, dim3(blocks256(n)), dim3(256), 0, st, *g, ps.cam, vk, out, ps.counts);
+        LAUNCH_CHECK("project_kernel");
+        size_t need = scan_temp_bytes(n);
+        if (!scratch || (int64_t)need > scratch_bytes) return fail(GSPLAT_ERR_WORKSPACE, "project scratch too small");
+        HIP_TRY(rocprim::inclusive_scan(scratch, need, ps.tiles, ps.offsets, (size_t)n, rocprim::plus<uint32_t>(), st));
+        hipLaunchKernelGGL(finish_counts_kernel, dim3(1), dim3(64), 0, st, ps.offsets, n, ps.counts);
+        LAUNCH_CHECK("finish_counts_kernel");
+    }
+    if (counts_host) HIP_TRY(hipMemcpyAsync(counts_host, ps.counts, sizeof(gsplat_counts), hipMemcpyDeviceToHost, st));
+    return GSPLAT_OK;
+}
+
+int gsplat_bin(int64_t n, int64_t n_pairs, const gsplat_view* v, const void* project_state, void* bin_state, void* scratch,
+               int64_t scratch_bytes, void* stream_) {
+    int rc = check_view(v);
+    if (rc) return rc;
+    if (n < 0 || n_pairs < 0 || n_pairs > 0xFFFFFFFFLL) return fail(GSPLAT_ERR_BAD_ARG, "n / n_pairs out of range");
+    if (!project_state || !bin_state) return fail(GSPLAT_ERR_BAD_ARG, "state is NULL");
+    hipStream_t st = (hipStream_t)stream_;
+    const ViewK vk = make_viewk(*v);
+    const int64_t nt = (int64_t)vk.tiles_x * vk.tiles_y;
+    ProjectState ps = carve_project((void*)project_state, n > 0 ? n : 1);
+    BinState bs = carve_bin(bin_state, n_pairs, nt);
+    HIP_TRY(hipMemsetAsync(bs.ranges, 0, nt * sizeof(uint2), st));
+    if (n_pairs == 0 || n == 0) return GSPLAT_OK;
+    BinScratch sc = carve_bin_scratch(scratch, n_pairs);
+    if (!scratch || sc.bytes > scratch_bytes) return fail(GSPLAT_ERR_WORKSPACE, "bin scratch too small");
+    hipLaunchKernelGGL(emit_pairs_kernel, dim3(blocks256(n)), dim3(256), 0, st, n, ps.rec2, ps.tiles, ps.offsets, vk.tiles_x, n_pairs,
+                       sc.keys_in, sc.vals_in);
+    LAUNCH_CHECK("emit_pairs_kernel");
+    unsigned tile_bits = 1;
+    while ((1LL << tile_bits) < nt) ++tile_bits;
+    size_t tb = sc.sort_temp_bytes;
+    HIP_TRY(rocprim::radix_sort_pairs(sc.sort_temp, tb, sc.keys_in, sc.keys_out, sc.vals_in, bs.sorted_ids, (size_t)n_pairs, 0u,
+                                      32u + tile_bits, st));
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(blocks256(n_pairs)), dim3(256), 0, st, n_pairs, sc.keys_out, bs.ranges);
+    LAUNCH_CHECK("tile_ranges_kernel");
+    return GSPLAT_OK;
+}
+
+int gsplat_rasterize_forward(int64_t n, int64_t n_pairs, const gsplat_view* v, const void* project_state, const void* bin_state,
+                             float* image, float* accum, void* stream_) {
+    int rc = check_view(v);
+    if (rc) return rc;
+    if (!project_state || !bin_state || !image) return fail(GSPLAT_ERR_BAD_ARG, "state / image is NULL");
+    hipStream_t st = (hipStream_t)stream_;
+    const ViewK vk = make_viewk(*v);
+    const int64_t nt = (int64_t)vk.tiles_x * vk.tiles_y;
+    ProjectState ps = carve_project((void*)project_state, n > 0 ? n : 1);
+    BinState bs = carve_bin((void*)bin_state, n_pairs, nt);
+    hipLaunchKernelGGL(raster_forward_kernel, dim3((unsigned)nt), dim3(64), 0, st, bs.ranges, bs.sorted_ids, ps.rec0, ps.rec1, ps.rec2,
+                       (int)nt, vk.tiles_x, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, image, accum);
+    LAUNCH_CHECK("raster_forward_kernel");
+    return GSPLAT_OK;
+}
+
+int gsplat_rasterize_backward(int64_t n, int64_t n_pairs, const gsplat_view* v, const void* project_state, const void* bin_state,
+                              const float* accum, const float* grad_image, float* grad2d, void* stream_) {
+    int rc = check_view(v);
+    if (rc) return rc;
+    if (!project_state || !bin_state || !accum || !grad_image || !grad2d) return fail(GSPLAT_ERR_BAD_ARG, "NULL argument");
+    hipStream_t st = (hipStream_t)stream_;
+    const ViewK vk = make_viewk(*v);
+    const int64_t nt = (int64_t)vk.tiles_x * vk.tiles_y;
+    ProjectState ps = carve_project((void*)project_state, n > 0 ? n : 1);
+    BinState bs = carve_bin((void*)bin_state, n_pairs, nt);
+    HIP_TRY(hipMemsetAsync(grad2d, 0, (size_t)(n > 0 ? n : 0) * 16 * sizeof(float), st));
+    if (n == 0 || n_pairs == 0) return GSPLAT_OK;
+    hipLaunchKernelGGL(raster_backward_kernel, dim3((unsigned)nt), dim3(64), 0, st, bs.ranges, bs.sorted_ids, ps.rec0, ps.rec1, ps.rec2,
+                       (int)nt, vk.tiles_x, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, accum, grad_image, grad2d);
+    LAUNCH_CHECK("raster_backward_kernel");
+    return GSPLAT_OK;
+}
+
+int gsplat_project_backward(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, const void* project_state,
+                            const float* grad2d, const gsplat_gaussian_grads* out, void* stream_) {
+    bool fused = false;
+    int rc = check_gaussians(g, &fused);
+    if (rc) return rc;
+    if ((rc = check_view(v))) return rc;
+    if (!c2w || !project_state || !grad2d || !out) return fail(GSPLAT_ERR_BAD_ARG, "NULL argument");
+    if (g->n == 0) return GSPLAT_OK;
+    if (!out->pos || !out->opacity_raw) return fail(GSPLAT_ERR_BAD_ARG, "grad pos / opacity_raw is NULL");
+    if (fused && !(out->scale_raw && out->q_raw && out->f_dc && out->f_rest)) return fail(GSPLAT_ERR_BAD_ARG, "fused grads incomplete");
+    if (!fused && !(out->color && out->sigma)) return fail(GSPLAT_ERR_BAD_ARG, "grad color / sigma is NULL");
+    hipStream_t st = (hipStream_t)stream_;
+    ProjectState ps = carve_project((void*)project_state, g->n);
+    const ViewK vk = make_viewk(*v);
+    if (fused)
+        hipLaunchKernelGGL(project_backward_kernel<true>, dim3(blocks256(g->n)), dim3(256), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out);
+    else
+        hipLaunchKernelGGL(project_backward_kernel<false>, dim3(blocks256(g->n)), dim3(256), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out);
+    LAUNCH_CHECK("project_backward_kernel");
+    return GSPLAT_OK;
+}
+
+int gsplat_build_sigma(int64_t n, const float* scale_raw, const float* q_raw, float* sigma, void* stream_) {
+    if (n < 0) return fail(GSPLAT_ERR_BAD_ARG, "n < 0");
+    if (n == 0) return GSPLAT_OK;
+    if (!scale_raw || !q_raw || !sigma) return fail(GSPLAT_ERR_BAD_ARG, "NULL argument");
+    hipLaunchKernelGGL(build_sigma_kernel, dim3(blocks256(n)), dim3(256), 0, (hipStream_t)stream_, n, scale_raw, q_raw, sigma);
+    LAUNCH_CHECK("build_sigma_kernel");
+    return GSPLAT_OK;
+}
+
+int gsplat_build_sigma_backward(int64_t n, const float* scale_raw, const float* q_raw, const float* grad_sigma, float* grad_scale_raw,
+                                float* grad_q_raw, void* stream_) {
+    if (n < 0) return fail(GSPLAT_ERR_BAD_ARG, "n < 0");
+    if (n == 0) return GSPLAT_OK;
+    if (!scale_raw || !q_raw || !grad_sigma || !grad_scale_raw || !grad_q_raw) return fail(GSPLAT_ERR_BAD_ARG, "NULL argument");
+    hipLaunchKernelGGL(build_sigma_backward_kernel, dim3(blocks256(n)), dim3(256), 0, (hipStream_t)stream_, n, scale_raw, q_raw,
+                       grad_sigma, grad_scale_raw, grad_q_raw);
+    LAUNCH_CHECK("build_sigma_backward_kernel");
+    return GSPLAT_OK;
+}
+
+int gsplat_evaluate_sh(int64_t n, const float* f_dc, const float* f_rest, const float* points, const float* c2w, float* color,
+                       void* stream_) {
+    if (n < 0) return fail(GSPLAT_ERR_BAD_ARG, "n < 0");
+    if (n == 0) return GSPLAT_OK;
+    if (!f_dc || !f_rest || !points || !c2w || !color) return fail(GSPLAT_ERR_BAD_ARG, "NULL argument");
+    hipLaunchKernelGGL(evaluate_sh_kernel, dim3(blocks256(n)), dim3(256), 0, (hipStream_t)stream_, n, f_dc, f_rest, points, c2w, color);
+    LAUNCH_CHECK("evaluate_sh_kernel");
+    return GSPLAT_OK;
+}
+
+int gsplat_evaluate_sh_backward(int64_t n, const float* f_dc, const float* f_rest, const float* points, const float* c2w,
+                                const float* grad_color, float* grad_f_dc, float* grad_f_rest, float* grad_points, void* stream_) {
+    if (n < 0) return fail(GSPLAT_ERR_BAD_ARG, "n < 0");
+    if (n == 0) return GSPLAT_OK;
+    if (!f_dc || !f_rest || !points || !c2w || !grad_color || !grad_f_dc || !grad_f_rest || !grad_points)
+        return fail(GSPLAT_ERR_BAD_ARG, "NULL argument");
+    hipLaunchKernelGGL(evaluate_sh_backward_kernel, dim3(blocks256(n)), dim3(256), 0, (hipStream_t)stream_, n, f_dc, f_rest, points, c2w,
+                       grad_color, grad_f_dc, grad_f_rest, grad_points);
+    LAUNCH_CHECK("evaluate_sh_backward_kernel");
+    return GSPLAT_OK;
+}
+
+}  // extern "C"

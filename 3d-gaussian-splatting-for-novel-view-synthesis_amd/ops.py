@@ -1,0 +1,326 @@
+"""PyTorch-ROCm host side of the hot path: autograd surface over the C ABI (ctypes, raw device pointers).
+
+Mirrors the reference's operator interface (same names, argument meaning, defaults and error behaviour):
+
+    render(pos, color, opacity_raw, sigma, c2w, H, W, fx, fy, cx, cy, near=0.01, far=100.0, pix_guard=32, T=16,
+           min_conis=1e-6, chi_square_clip=6.25, alpha_max=0.99, alpha_cutoff=1/128.)      reference render.py:62-64
+    build_sigma_from_params(scale_raw, q_raw)                                               reference gaussian.py:71
+    evaluate_sh(f_dc, f_rest, points, c2w)                                   reference spherical_harmonics.py:70
+
+plus the fused entry `render_gaussians(...)`, which takes the six raw parameter tensors and folds the covariance build
+and the SH evaluation into the projection kernel (the Sigma[N,3,3] and colour[N,3] tensors are never materialised).
+
+PyTorch is plumbing here (device memory, streams, autograd bookkeeping); all arithmetic runs in the HIP library.
+There is no CPU path: CPU tensors, or a missing library, raise.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi
+
+OFFSCREEN_MSG = "All projected points are off-screen"      # reference render.py:236
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _f32(t, shape, name):
+    """Detached, contiguous fp32 view/copy of a tensor argument (reference tensors are already fp32 contiguous)."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} is on {t.device}: the MI355X rasterizer needs GPU tensors (there is no CPU fallback)")
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class _Workspace:
+    """Grow-only scratch buffers and one pinned counter block per device (scratch is dead after each call)."""
+
+    def __init__(self):
+        self.scratch = {}
+        self.pinned = {}
+
+    def get_scratch(self, device, nbytes):
+        key = (device.type, device.index)
+        buf = self.scratch.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+            self.scratch[key] = buf
+        return buf
+
+    def get_pinned(self, device):
+        key = (device.type, device.index)
+        buf = self.pinned.get(key)
+        if buf is None:
+            buf = torch.zeros(C.sizeof(_abi.Counts), dtype=torch.uint8).pin_memory()
+            self.pinned[key] = buf
+        return buf
+
+
+_ws = _Workspace()
+
+
+def _make_gaussians(n, pos, opacity_raw, color=None, sigma=None, scale_raw=None, q_raw=None, f_dc=None, f_rest=None):
+    return _abi.Gaussians(n, _p(pos), _p(opacity_raw), _p(color), _p(sigma), _p(scale_raw), _p(q_raw), _p(f_dc), _p(f_rest))
+
+
+class _Frame:
+    """Everything the backward pass needs from one forward call."""
+    __slots__ = ("view", "n", "n_pairs", "proj_state", "bin_state", "accum", "fused", "inputs", "c2w", "empty")
+
+
+def _forward_impl(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad):
+    lib = _abi.lib()
+    dev = pos.device
+    n = pos.shape[0]
+    pos32 = _f32(pos, (n, 3), "pos")
+    opa32 = _f32(opacity_raw.reshape(-1), (n,), "opacity_raw")
+    c2w32 = _f32(c2w, (4, 4), "c2w")
+    if fused:
+        ins = dict(scale_raw=_f32(a, (n, 3), "scale_raw"), q_raw=_f32(b, (n, 4), "q_raw"), f_dc=_f32(c, (n, 3), "f_dc"),
+                   f_rest=_f32(d, (n, 45), "f_rest"))
+    else:
+        ins = dict(color=_f32(a, (n, 3), "color"), sigma=_f32(b, (n, 3, 3), "sigma"))
+    g = _make_gaussians(n, pos32, opa32, **ins)
+    st = _stream_ptr(dev)
+    fr = _Frame()
+    fr.view, fr.n, fr.fused, fr.c2w, fr.empty = view, n, fused, c2w32, False
+    fr.inputs = dict(pos=pos32, opacity_raw=opa32, **ins)
+    H, W = view.H, view.W
+    with torch.cuda.device(dev):
+        fr.proj_state = torch.empty(lib.gsplat_project_state_bytes(n), dtype=torch.uint8, device=dev)
+        sbytes = lib.gsplat_project_scratch_bytes(n)
+        scratch = _ws.get_scratch(dev, sbytes)
+        pinned = _ws.get_pinned(dev)
+        _abi.check(lib.gsplat_project(C.byref(g), _p(c2w32), C.byref(view), _p(fr.proj_state), _p(scratch), scratch.numel(),
+                                      C.c_void_p(pinned.data_ptr()), st), "gsplat_project")
+        # the one host synchronisation of the forward pass: the pair count sizes the binning buffers, and the
+        # reference's empty / off-screen conventions need the survivor counts
+        torch.cuda.current_stream(dev).synchronize()
+        counts = _abi.Counts.from_buffer_copy(pinned.numpy().tobytes())
+        scene = lib.gsplat_classify_counts(C.byref(counts))
+        if scene == _abi.GSPLAT_SCENE_ALL_OFFSCREEN:
+            raise Exception(OFFSCREEN_MSG)
+        image = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+        if scene == _abi.GSPLAT_SCENE_ALL_CULLED:
+            fr.empty = True
+            fr.proj_state = None
+            return image.zero_(), fr, counts
+        fr.n_pairs = int(counts.n_pairs)
+        fr.bin_state = torch.empty(lib.gsplat_bin_state_bytes(fr.n_pairs, C.byref(view)), dtype=torch.uint8, device=dev)
+        sbytes = lib.gsplat_bin_scratch_bytes(n, fr.n_pairs)
+        scratch = _ws.get_scratch(dev, sbytes)
+        _abi.check(lib.gsplat_bin(n, fr.n_pairs, C.byref(view), _p(fr.proj_state), _p(fr.bin_state), _p(scratch), scratch.numel(),
+                                  st), "gsplat_bin")
+        fr.accum = torch.empty((H, W, 3), dtype=torch.float32, device=dev) if need_grad else None
+        _abi.check(lib.gsplat_rasterize_forward(n, fr.n_pairs, C.byref(view), _p(fr.proj_state), _p(fr.bin_state), _p(image),
+                                                _p(fr.accum), st), "gsplat_rasterize_forward")
+    return image, fr, counts
+
+
+def _backward_impl(fr, grad_image):
+    """Returns a dict name -> fp32 gradient tensor for every input of the forward call."""
+    lib = _abi.lib()
+    ins = fr.inputs
+    dev = ins["pos"].device
+    if fr.empty or fr.n == 0:
+        return {k: torch.zeros_like(v) for k, v in ins.items()}
+    gi = _f32(grad_image, (fr.view.H, fr.view.W, 3), "grad_image")
+    st = _stream_ptr(dev)
+    with torch.cuda.device(dev):
+        grad2d = torch.empty((fr.n, 16), dtype=torch.float32, device=dev)
+        _abi.check(lib.gsplat_rasterize_backward(fr.n, fr.n_pairs, C.byref(fr.view), _p(fr.proj_state), _p(fr.bin_state),
+                                                 _p(fr.accum), _p(gi), _p(grad2d), st), "gsplat_rasterize_backward")
+        out = {k: torch.empty_like(v) for k, v in ins.items()}
+        g = _make_gaussians(fr.n, **ins)
+        gg = _abi.GaussianGrads(_p(out["pos"]), _p(out["opacity_raw"]), _p(out.get("color")), _p(out.get("sigma")),
+                                _p(out.get("scale_raw")), _p(out.get("q_raw")), _p(out.get("f_dc")), _p(out.get("f_rest")))
+        _abi.check(lib.gsplat_project_backward(C.byref(g), _p(fr.c2w), C.byref(fr.view), _p(fr.proj_state), _p(grad2d),
+                                               C.byref(gg), st), "gsplat_project_backward")
+    return out
+
+
+class _RenderFn(torch.autograd.Function):
+    """Autograd node for both entry points; gradients for the tensor inputs only (c2w and scalars get None)."""
+
+    @staticmethod
+    def forward(ctx, fused, view, c2w, pos, opacity_raw, a, b, c, d):
+        need = any(ctx.needs_input_grad)
+        image, fr, counts = _forward_impl(fused, view, c2w, pos, opacity_raw, a, b, c, d, need)
+        ctx.frame = fr
+        ctx.dtypes = [t.dtype if isinstance(t, torch.Tensor) else None for t in (pos, opacity_raw, a, b, c, d)]
+        ctx.opa_shape = opacity_raw.shape
+        ctx.counts = (counts.n_survivors, counts.n_visible, int(counts.n_pairs))
+        return image if pos.dtype == torch.float32 else image.to(pos.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_image):
+        fr = ctx.frame
+        g = _backward_impl(fr, grad_image)
+        names = ("pos", "opacity_raw") + (("scale_raw", "q_raw", "f_dc", "f_rest") if fr.fused else ("color", "sigma", None, None))
+        outs = []
+        for i, nm in enumerate(names):
+            if nm is None or not ctx.needs_input_grad[3 + i]:
+                outs.append(None)
+                continue
+            t = g[nm]
+            if nm == "opacity_raw":
+                t = t.reshape(ctx.opa_shape)
+            outs.append(t if ctx.dtypes[i] == torch.float32 else t.to(ctx.dtypes[i]))
+        return (None, None, None, *outs)
+
+
+def _view(H, W, fx, fy, cx, cy, near, far, pix_guard, T, min_conis, chi_square_clip, alpha_max, alpha_cutoff):
+    # H, W may arrive as 0-d tensors from DataLoader collate (reference scripts/train.py:499)
+    if int(T) != 16:
+        raise NotImplementedError("the HIP rasterizer is built for T=16 tiles (the rendered image does not depend on T)")
+    return _abi.make_view(int(H), int(W), float(fx), float(fy), float(cx), float(cy), near, far, pix_guard, T, min_conis,
+                          chi_square_clip, alpha_max, alpha_cutoff)
+
+
+def render(pos, color, opacity_raw, sigma, c2w, H, W, fx, fy, cx, cy, near=0.01, far=100.0, pix_guard=32, T=16,
+           min_conis=1e-6, chi_square_clip=6.25, alpha_max=0.99, alpha_cutoff=1 / 128.):
+    """Drop-in for the reference render() (gaussian_splatting/render.py:62-410).
+
+    Returns the image [H, W, 3] in [0, 1], same dtype/device as `pos`, differentiable w.r.t. pos, color, opacity_raw
+    and sigma.  No opacity / frustum / finite survivor -> zero image with zero gradients; survivors but none on
+    screen -> Exception("All projected points are off-screen"), as in the reference.
+    """
+    view = _view(H, W, fx, fy, cx, cy, near, far, pix_guard, T, min_conis, chi_square_clip, alpha_max, alpha_cutoff)
+    return _RenderFn.apply(False, view, c2w, pos, opacity_raw, color, sigma, None, None)
+
+
+def render_gaussians(pos, f_dc, f_rest, opacity_raw, scale_raw, q_raw, c2w, H, W, fx, fy, cx, cy, near=0.01, far=100.0,
+                     pix_guard=32, T=16, min_conis=1e-6, chi_square_clip=6.25, alpha_max=0.99, alpha_cutoff=1 / 128.):
+    """Fused entry: render(pos, evaluate_sh(f_dc, f_rest, pos, c2w), opacity_raw, build_sigma_from_params(scale_raw,
+    q_raw), c2w, ...) in one pass (the reference's three-call sequence, scripts/train.py:463,502,505-508)."""
+    view = _view(H, W, fx, fy, cx, cy, near, far, pix_guard, T, min_conis, chi_square_clip, alpha_max, alpha_cutoff)
+    return _RenderFn.apply(True, view, c2w, pos, opacity_raw, scale_raw, q_raw, f_dc, f_rest)
+
+
+def render_stats(image):
+    """(n_survivors, n_visible V, n_pairs P) of the render() / render_gaussians() call that produced `image`."""
+    fn = image.grad_fn
+    return getattr(fn, "counts", None) if fn is not None else None
+
+
+class _BuildSigmaFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scale_raw, q_raw):
+        lib = _abi.lib()
+        n = scale_raw.shape[0]
+        sr, qr = _f32(scale_raw, (n, 3), "scale_raw"), _f32(q_raw, (n, 4), "q_raw")
+        out = torch.empty((n, 3, 3), dtype=torch.float32, device=sr.device)
+        with torch.cuda.device(sr.device):
+            _abi.check(lib.gsplat_build_sigma(n, _p(sr), _p(qr), _p(out), _stream_ptr(sr.device)), "gsplat_build_sigma")
+        ctx.save_for_backward(sr, qr)
+        ctx.dtypes = (scale_raw.dtype, q_raw.dtype)
+        return out if scale_raw.dtype == torch.float32 else out.to(scale_raw.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_sigma):
+        lib = _abi.lib()
+        sr, qr = ctx.saved_tensors
+        n = sr.shape[0]
+        gs = _f32(grad_sigma, (n, 3, 3), "grad_sigma")
+        gsr, gqr = torch.empty_like(sr), torch.empty_like(qr)
+        with torch.cuda.device(sr.device):
+            _abi.check(lib.gsplat_build_sigma_backward(n, _p(sr), _p(qr), _p(gs), _p(gsr), _p(gqr), _stream_ptr(sr.device)),
+                       "gsplat_build_sigma_backward")
+        return gsr.to(ctx.dtypes[0]), gqr.to(ctx.dtypes[1])
+
+
+def build_sigma_from_params(scale_raw, q_raw):
+    """Drop-in for the reference build_sigma_from_params (gaussian_splatting/gaussian.py:71-127): Sigma = R S S R^T."""
+    return _BuildSigmaFn.apply(scale_raw, q_raw)
+
+
+class _EvaluateShFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f_dc, f_rest, points, c2w):
+        lib = _abi.lib()
+        n = points.shape[0]
+        if f_rest.shape[-1] != 45:
+            # the reference raises RuntimeError for any other width
+            raise RuntimeError(f"evaluate_sh needs f_rest of width 45 (degree-3 SH), got {tuple(f_rest.shape)}")
+        dc, rest = _f32(f_dc, (n, 3), "f_dc"), _f32(f_rest, (n, 45), "f_rest")
+        pts, cam = _f32(points, (n, 3), "points"), _f32(c2w, (4, 4), "c2w")
+        out = torch.empty((n, 3), dtype=torch.float32, device=pts.device)
+        with torch.cuda.device(pts.device):
+            _abi.check(lib.gsplat_evaluate_sh(n, _p(dc), _p(rest), _p(pts), _p(cam), _p(out), _stream_ptr(pts.device)),
+                       "gsplat_evaluate_sh")
+        ctx.save_for_backward(dc, rest, pts, cam)
+        ctx.dtypes = (f_dc.dtype, f_rest.dtype, points.dtype)
+        return out if points.dtype == torch.float32 else out.to(points.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_color):
+        lib = _abi.lib()
+        dc, rest, pts, cam = ctx.saved_tensors
+        n = pts.shape[0]
+        gc = _f32(grad_color, (n, 3), "grad_color")
+        gdc, grest, gpts = torch.empty_like(dc), torch.empty_like(rest), torch.empty_like(pts)
+        with torch.cuda.device(pts.device):
+            _abi.check(lib.gsplat_evaluate_sh_backward(n, _p(dc), _p(rest), _p(pts), _p(cam), _p(gc), _p(gdc), _p(grest),
+                                                       _p(gpts), _stream_ptr(pts.device)), "gsplat_evaluate_sh_backward")
+        return gdc.to(ctx.dtypes[0]), grest.to(ctx.dtypes[1]), gpts.to(ctx.dtypes[2]), None
+
+
+def evaluate_sh(f_dc, f_rest, points, c2w):
+    """Drop-in for the reference evaluate_sh (gaussian_splatting/spherical_harmonics.py:70-166): degree-3 real SH,
+    channel-major f_rest, sigmoid output."""
+    return _EvaluateShFn.apply(f_dc, f_rest, points, c2w)
+
+
+# ---- the small helper functions the reference namespace also exports (host-side, not on the hot path) ----
+
+HARMONICS = {   # reference gaussian_splatting/spherical_harmonics.py:50-67
+    'SH_C0': 0.28209479177387814, 'SH_C1_x': 0.4886025119029199, 'SH_C1_y': 0.4886025119029199,
+    'SH_C1_z': 0.4886025119029199, 'SH_C2_xy': 1.0925484305920792, 'SH_C2_xz': 1.0925484305920792,
+    'SH_C2_yz': 1.0925484305920792, 'SH_C2_zz': 0.31539156525252005, 'SH_C2_xx_yy': 0.5462742152960396,
+    'SH_C3_yxx_yyy': 0.5900435899266435, 'SH_C3_xyz': 2.890611442640554, 'SH_C3_yzz_yxx_yyy': 0.4570457994644658,
+    'SH_C3_zzz_zxx_zyy': 0.3731763325901154, 'SH_C3_xzz_xxx_xyy': 0.4570457994644658,
+    'SH_C3_zxx_zyy': 1.445305721320277, 'SH_C3_xxx_xyy': 0.5900435899266435,
+}
+
+
+def quat_to_rotmat(quat):
+    """(x, y, z, w) quaternions [..., 4] -> rotation matrices [..., 3, 3], no normalisation (reference gaussian.py:24-68)."""
+    x, y, z, w = quat.unbind(-1)
+    m = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                     2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                     2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1)
+    return m.reshape(quat.shape[:-1] + (3, 3))
+
+
+def inv2x2(M, eps=1e-12):
+    """Batched 2x2 inverse with the determinant clamped at eps (reference utils.py:152-191)."""
+    det = (M[:, 0, 0] * M[:, 1, 1] - M[:, 0, 1] * M[:, 1, 0]).clamp(min=eps)
+    adj = torch.stack([M[:, 1, 1], -M[:, 0, 1], -M[:, 1, 0], M[:, 0, 0]], -1).reshape(-1, 2, 2)
+    return adj / det.reshape(-1, 1, 1)
+
+
+def scale_intrinsics(H, W, H_src, W_src, fx, fy, cx, cy):
+    """Rescale pinhole intrinsics to another resolution (reference utils.py:194-238)."""
+    sx, sy = W / W_src, H / H_src
+    return fx * sx, fy * sy, cx * sx, cy * sy
+
+
+def project_points(pc, c2w, fx, fy, cx, cy):
+    """World points -> (uv [N,2], x, y, z) in the camera frame (reference utils.py:99-149)."""
+    rt = c2w[:3, :3].t()
+    cam = pc @ rt.t() - rt @ c2w[:3, 3]
+    x, y, z = cam[:, 0], cam[:, 1], cam[:, 2]
+    return torch.stack([fx * x / z + cx, fy * y / z + cy], -1), x, y, z

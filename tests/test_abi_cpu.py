@@ -1,0 +1,98 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads and exports every symbol include/*.h declares
+(no compute calls without a GPU), the Python mirror agrees with the header, and the product fails loudly on CPU."""
+import ctypes as C
+import importlib
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+abi = importlib.import_module("3d-gaussian-splatting-for-novel-view-synthesis_amd._abi")
+
+
+def _header_functions():
+    txt = open(os.path.join(ROOT, "include", "gsplat_mi355x.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(gsplat_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_and_python_mirror_agree():
+    names = _header_functions()
+    assert len(names) >= 16
+    assert sorted(abi.SIGNATURES) == names
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(abi.LIB_PATH), "build the library first: python __graft_entry__.py"
+    lib = C.CDLL(abi.LIB_PATH)
+    for name in _header_functions():
+        assert hasattr(lib, name), f"{name} is declared in include/gsplat_mi355x.h but not exported"
+    assert abi.lib().gsplat_abi_version() == abi.ABI_VERSION
+
+
+def test_struct_layouts_match_header():
+    # sizes the C side static_asserts / uses: gsplat_view 14 x 4 B, gsplat_counts 24 B, 9 and 8 pointer-sized fields
+    assert C.sizeof(abi.View) == 56
+    assert C.sizeof(abi.Counts) == 24
+    assert C.sizeof(abi.Gaussians) == 9 * 8
+    assert C.sizeof(abi.GaussianGrads) == 8 * 8
+
+
+def test_size_queries_are_pure_host_functions():
+    lib = abi.lib()
+    v = abi.make_view(1080, 1920, 1100.0, 1100.0, 960.0, 540.0)
+    n, p = 1_000_000, 2_720_508
+    assert lib.gsplat_project_state_bytes(n) >= n * 56
+    assert lib.gsplat_bin_state_bytes(p, C.byref(v)) >= p * 4 + 8160 * 8
+    assert lib.gsplat_bin_scratch_bytes(n, p) >= p * 20
+    assert lib.gsplat_project_scratch_bytes(n) > 0
+
+
+def test_scene_classification_mirrors_reference_conventions():
+    lib = abi.lib()
+    assert lib.gsplat_classify_counts(C.byref(abi.Counts(0, 0, 0, 0, 0))) == abi.GSPLAT_SCENE_ALL_CULLED
+    assert lib.gsplat_classify_counts(C.byref(abi.Counts(5, 0, 0, 0, 0))) == abi.GSPLAT_SCENE_ALL_OFFSCREEN
+    assert lib.gsplat_classify_counts(C.byref(abi.Counts(5, 3, 7, 4, 0))) == abi.GSPLAT_SCENE_OK
+
+
+def test_bad_arguments_are_rejected_without_touching_the_gpu():
+    lib = abi.lib()
+    v = abi.make_view(64, 64, 50.0, 50.0, 32.0, 32.0)
+    assert lib.gsplat_project(None, None, C.byref(v), None, None, 0, None, None) == 1
+    assert b"NULL" in lib.gsplat_last_error()
+    v8 = abi.make_view(64, 64, 50.0, 50.0, 32.0, 32.0, T=8)
+    assert lib.gsplat_bin(0, 0, C.byref(v8), None, None, None, 0, None) == 1
+    assert b"T=16" in lib.gsplat_last_error()
+
+
+def test_no_cpu_fallback(gs):
+    z = torch.zeros
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        gs.render(z(4, 3), z(4, 3), z(4), z(4, 3, 3), torch.eye(4), 16, 16, 10., 10., 8., 8.)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        gs.build_sigma_from_params(z(4, 3), z(4, 4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        gs.evaluate_sh(z(4, 3), z(4, 45), z(4, 3), torch.eye(4))
+    with pytest.raises(NotImplementedError):
+        gs.render(z(4, 3), z(4, 3), z(4), z(4, 3, 3), torch.eye(4), 16, 16, 10., 10., 8., 8., T=8)
+
+
+def test_small_helpers_match_oracle():
+    from oracle import torch_port as tp
+    gs = importlib.import_module("3d-gaussian-splatting-for-novel-view-synthesis_amd")
+    g = torch.Generator().manual_seed(3)
+    q = torch.randn(7, 4, generator=g, dtype=torch.float64)
+    assert torch.allclose(gs.quat_to_rotmat(q), tp.rotmat_from_quat(q))
+    m = torch.randn(9, 2, 2, generator=g, dtype=torch.float64)
+    assert torch.allclose(gs.inv2x2(m), tp.inv2x2(m))
+    assert gs.scale_intrinsics(540, 960, 1080, 1920, 1100., 1090., 961.5, 538.25) == tp.scale_intrinsics(
+        540, 960, 1080, 1920, 1100., 1090., 961.5, 538.25)
+    pc = torch.randn(11, 3, generator=g, dtype=torch.float64) + torch.tensor([0, 0, 5.0])
+    c2w = torch.eye(4, dtype=torch.float64)
+    c2w[:3, 3] = torch.tensor([0.1, -0.2, 0.3])
+    a, b = gs.project_points(pc, c2w, 500., 510., 320., 240.), tp.project_points(pc, c2w, 500., 510., 320., 240.)
+    for x, y in zip(a, b):
+        assert torch.allclose(x, y)
+    assert abs(gs.HARMONICS['SH_C3_xyz'] - tp.SH_K[10]) < 1e-15 and len(gs.HARMONICS) == 16
