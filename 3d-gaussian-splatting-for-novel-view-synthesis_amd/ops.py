@@ -99,6 +99,9 @@ def _forward_impl(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad):
     fr.view, fr.n, fr.fused, fr.c2w, fr.empty = view, n, fused, c2w32, False
     fr.inputs = dict(pos=pos32, opacity_raw=opa32, **ins)
     H, W = view.H, view.W
+    if n == 0:      # nothing survives by construction: the reference returns the zero image (render.py:109-112)
+        fr.empty, fr.proj_state = True, None
+        return torch.zeros((H, W, 3), dtype=torch.float32, device=dev), fr, _abi.Counts(0, 0, 0, 0, 0)
     with torch.cuda.device(dev):
         fr.proj_state = torch.empty(lib.gsplat_project_state_bytes(n), dtype=torch.uint8, device=dev)
         sbytes = lib.gsplat_project_scratch_bytes(n)
