@@ -72,6 +72,52 @@ class _Workspace:
 _ws = _Workspace()
 
 
+class StageTimer:
+    """Optional per-stage timing with HIP events recorded on the stream the kernels are launched on (torch's current
+    stream).  bench.py installs one with `set_stage_timer`; when none is installed the hooks cost nothing."""
+
+    def __init__(self):
+        self.events = []          # (stage, start_event, end_event)
+
+    def totals_ms(self):
+        """stage -> (launches, total milliseconds); call after a device synchronise."""
+        out = {}
+        for name, a, b in self.events:
+            n, t = out.get(name, (0, 0.0))
+            out[name] = (n + 1, t + a.elapsed_time(b))
+        return out
+
+    def reset(self):
+        self.events = []
+
+
+_timer = None
+
+
+def set_stage_timer(timer):
+    global _timer
+    _timer = timer
+
+
+class _stage:
+    __slots__ = ("name", "a")
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _timer is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if _timer is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            _timer.events.append((self.name, self.a, b))
+        return False
+
+
 def _make_gaussians(n, pos, opacity_raw, color=None, sigma=None, scale_raw=None, q_raw=None, f_dc=None, f_rest=None):
     return _abi.Gaussians(n, _p(pos), _p(opacity_raw), _p(color), _p(sigma), _p(scale_raw), _p(q_raw), _p(f_dc), _p(f_rest))
 
@@ -107,8 +153,9 @@ def _forward_impl(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad):
         sbytes = lib.gsplat_project_scratch_bytes(n)
         scratch = _ws.get_scratch(dev, sbytes)
         pinned = _ws.get_pinned(dev)
-        _abi.check(lib.gsplat_project(C.byref(g), _p(c2w32), C.byref(view), _p(fr.proj_state), _p(scratch), scratch.numel(),
-                                      C.c_void_p(pinned.data_ptr()), st), "gsplat_project")
+        with _stage("project"):
+            _abi.check(lib.gsplat_project(C.byref(g), _p(c2w32), C.byref(view), _p(fr.proj_state), _p(scratch),
+                                          scratch.numel(), C.c_void_p(pinned.data_ptr()), st), "gsplat_project")
         # the one host synchronisation of the forward pass: the pair count sizes the binning buffers, and the
         # reference's empty / off-screen conventions need the survivor counts
         torch.cuda.current_stream(dev).synchronize()
@@ -125,11 +172,13 @@ def _forward_impl(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad):
         fr.bin_state = torch.empty(lib.gsplat_bin_state_bytes(fr.n_pairs, C.byref(view)), dtype=torch.uint8, device=dev)
         sbytes = lib.gsplat_bin_scratch_bytes(n, fr.n_pairs)
         scratch = _ws.get_scratch(dev, sbytes)
-        _abi.check(lib.gsplat_bin(n, fr.n_pairs, C.byref(view), _p(fr.proj_state), _p(fr.bin_state), _p(scratch), scratch.numel(),
-                                  st), "gsplat_bin")
+        with _stage("bin"):
+            _abi.check(lib.gsplat_bin(n, fr.n_pairs, C.byref(view), _p(fr.proj_state), _p(fr.bin_state), _p(scratch),
+                                      scratch.numel(), st), "gsplat_bin")
         fr.accum = torch.empty((H, W, 3), dtype=torch.float32, device=dev) if need_grad else None
-        _abi.check(lib.gsplat_rasterize_forward(n, fr.n_pairs, C.byref(view), _p(fr.proj_state), _p(fr.bin_state), _p(image),
-                                                _p(fr.accum), st), "gsplat_rasterize_forward")
+        with _stage("raster_forward"):
+            _abi.check(lib.gsplat_rasterize_forward(n, fr.n_pairs, C.byref(view), _p(fr.proj_state), _p(fr.bin_state),
+                                                    _p(image), _p(fr.accum), st), "gsplat_rasterize_forward")
     return image, fr, counts
 
 
@@ -144,14 +193,16 @@ def _backward_impl(fr, grad_image):
     st = _stream_ptr(dev)
     with torch.cuda.device(dev):
         grad2d = torch.empty((fr.n, 16), dtype=torch.float32, device=dev)
-        _abi.check(lib.gsplat_rasterize_backward(fr.n, fr.n_pairs, C.byref(fr.view), _p(fr.proj_state), _p(fr.bin_state),
-                                                 _p(fr.accum), _p(gi), _p(grad2d), st), "gsplat_rasterize_backward")
+        with _stage("raster_backward"):
+            _abi.check(lib.gsplat_rasterize_backward(fr.n, fr.n_pairs, C.byref(fr.view), _p(fr.proj_state), _p(fr.bin_state),
+                                                     _p(fr.accum), _p(gi), _p(grad2d), st), "gsplat_rasterize_backward")
         out = {k: torch.empty_like(v) for k, v in ins.items()}
         g = _make_gaussians(fr.n, **ins)
         gg = _abi.GaussianGrads(_p(out["pos"]), _p(out["opacity_raw"]), _p(out.get("color")), _p(out.get("sigma")),
                                 _p(out.get("scale_raw")), _p(out.get("q_raw")), _p(out.get("f_dc")), _p(out.get("f_rest")))
-        _abi.check(lib.gsplat_project_backward(C.byref(g), _p(fr.c2w), C.byref(fr.view), _p(fr.proj_state), _p(grad2d),
-                                               C.byref(gg), st), "gsplat_project_backward")
+        with _stage("project_backward"):
+            _abi.check(lib.gsplat_project_backward(C.byref(g), _p(fr.c2w), C.byref(fr.view), _p(fr.proj_state), _p(grad2d),
+                                                   C.byref(gg), st), "gsplat_project_backward")
     return out
 
 
@@ -165,7 +216,8 @@ class _RenderFn(torch.autograd.Function):
         ctx.frame = fr
         ctx.dtypes = [t.dtype if isinstance(t, torch.Tensor) else None for t in (pos, opacity_raw, a, b, c, d)]
         ctx.opa_shape = opacity_raw.shape
-        ctx.counts = (counts.n_survivors, counts.n_visible, int(counts.n_pairs))
+        global _last_counts
+        ctx.counts = _last_counts = (counts.n_survivors, counts.n_visible, int(counts.n_pairs))
         return image if pos.dtype == torch.float32 else image.to(pos.dtype)
 
     @staticmethod
@@ -213,10 +265,14 @@ def render_gaussians(pos, f_dc, f_rest, opacity_raw, scale_raw, q_raw, c2w, H, W
     return _RenderFn.apply(True, view, c2w, pos, opacity_raw, scale_raw, q_raw, f_dc, f_rest)
 
 
-def render_stats(image):
-    """(n_survivors, n_visible V, n_pairs P) of the render() / render_gaussians() call that produced `image`."""
-    fn = image.grad_fn
-    return getattr(fn, "counts", None) if fn is not None else None
+_last_counts = None
+
+
+def render_stats(image=None):
+    """(n_survivors, n_visible V, n_pairs P) of the call that produced `image` (or of the most recent call)."""
+    fn = image.grad_fn if image is not None else None
+    got = getattr(fn, "counts", None) if fn is not None else None
+    return got if got is not None else _last_counts
 
 
 class _BuildSigmaFn(torch.autograd.Function):
