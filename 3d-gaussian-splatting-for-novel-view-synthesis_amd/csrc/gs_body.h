@@ -11,13 +11,17 @@ struct alignas(16) f4 { float x, y, z, w; };
 GS_HD uint32_t f2u(float f) { union { float f; uint32_t u; } c; c.f = f; return c.u; }
 GS_HD float u2f(uint32_t u) { union { float f; uint32_t u; } c; c.u = u; return c.f; }
 
-// Projected record, 48 B per Gaussian in three 16-B streams (SoA of float4):
-//   rec0 = (u, v, A11, A12)   rec1 = (A22, opacity, r, g)   rec2 = (b, depth z, rect lo, rect hi)
-// rect lo = tx0 | ty0 << 16, rect hi = tx1 | ty1 << 16 (inclusive tile rectangle).
+struct u2 { uint32_t x, y; };
+
+// Projected record, 48 B per Gaussian in three 16-B streams (SoA of float4) + the tile rectangle:
+//   rec0 = (u, v, A11, A12)   rec1 = (A22, opacity, ex, ey)   rec2 = (r, g, b, depth z)
+//   rect = (tx0 | ty0 << 16, tx1 | ty1 << 16)   inclusive tile rectangle
+// (ex, ey) are the half-extents of {q <= chi_square_clip}: the rasterizer culls with them at staging time.
 struct Records {
     f4* rec0;
     f4* rec1;
     f4* rec2;
+    u2* rect;
     uint32_t* tiles;      // tiles touched per Gaussian (0 = not visible)
 };
 
@@ -78,8 +82,9 @@ GS_HD int project_one(int64_t i, const gsplat_gaussians& g, bool fused, Coef coe
         }
         nt = (uint32_t)((o.tx1 - o.tx0 + 1) * (o.ty1 - o.ty0 + 1));
         out.rec0[i] = f4{o.u, o.v, o.A11, o.A12};
-        out.rec1[i] = f4{o.A22, o.opacity, rgb[0], rgb[1]};
-        out.rec2[i] = f4{rgb[2], o.z, u2f((uint32_t)o.tx0 | ((uint32_t)o.ty0 << 16)), u2f((uint32_t)o.tx1 | ((uint32_t)o.ty1 << 16))};
+        out.rec1[i] = f4{o.A22, o.opacity, o.ex, o.ey};
+        out.rec2[i] = f4{rgb[0], rgb[1], rgb[2], o.z};
+        out.rect[i] = u2{(uint32_t)o.tx0 | ((uint32_t)o.ty0 << 16), (uint32_t)o.tx1 | ((uint32_t)o.ty1 << 16)};
     }
     out.tiles[i] = nt;
     return o.vis;

@@ -218,6 +218,7 @@ struct ProjMid {
 struct Proj {
     float u, v, z;
     float A11, A12, A22;          // conic
+    float ex, ey;                 // half-extents of {q <= chi_square_clip} along u and v (+inf if the conic is not PD)
     float opacity;
     int tx0, ty0, tx1, ty1;       // inclusive tile rectangle
     int vis;                      // VIS_*
@@ -301,6 +302,20 @@ GS_HD void project_gaussian(const float p[3], const float S[6], float o_raw, con
     o.A11 = fmaxf(m.i00, vk.min_conis);
     o.A12 = -m.b2 / m.sdet;
     o.A22 = fmaxf(m.i11, vk.min_conis);
+    // Tight bounding box of the region the rasterizer can touch: q(du,dv) <= chi  =>  |du| <= sqrt(chi A22 / D),
+    // |dv| <= sqrt(chi A11 / D), D = A11 A22 - A12^2, derived from the conic actually used (after its clamps).
+    // Padded (1e-4 relative + 1e-2 px) so that fp32 rounding of q can never put a covered pixel outside the box.
+    {
+        const float D = o.A11 * o.A22 - o.A12 * o.A12;
+        if (D > 0.f && o.A11 > 0.f && o.A22 > 0.f) {
+            o.ex = sqrtf(vk.chi_clip * o.A22 / D) * 1.0001f + 0.01f;
+            o.ey = sqrtf(vk.chi_clip * o.A11 / D) * 1.0001f + 0.01f;
+            if (!(o.ex < 1e30f)) o.ex = 1e30f;
+            if (!(o.ey < 1e30f)) o.ey = 1e30f;
+        } else {
+            o.ex = 1e30f; o.ey = 1e30f;
+        }
+    }
     if (!(umax >= 0.f && umin < (float)vk.W && vmax >= 0.f && vmin < (float)vk.H)) { o.vis = VIS_OFFSCREEN; return; }
     const float wm = (float)(vk.W - 1), hm = (float)(vk.H - 1);
     o.tx0 = (int)clampf_(umin, 0.f, wm) / vk.tile;

@@ -7,7 +7,7 @@
 //   K3 emit_pairs_kernel        (tile << 32 | depth bits, id) per covered tile       [F11]
 //   K4 rocprim radix_sort_pairs stable -> (tile, depth, id) order                    [F9, F12]
 //   K5 tile_ranges_kernel       per-tile [start, end)                                [F12]
-//   K6 raster_forward_kernel    one wave64 per 16x16 tile, 4 pixels per lane         [F14, F15]
+//   K6 raster_forward_kernel    one wave64 per 16x8 half tile, 2 pixels per lane     [F14, F15]
 //   K7 raster_backward_kernel   same traversal, analytic gradients, wave reduction   [B1]
 //   K8 project_backward_kernel  chain rule to the reference's input tensors          [B2, B3]
 //
@@ -60,6 +60,7 @@ struct ProjectState {
     Camera* cam;
     DevCounts* counts;
     f4 *rec0, *rec1, *rec2;
+    u2* rect;
     uint32_t* tiles;
     uint32_t* offsets;       // inclusive prefix sum of tiles
     int64_t bytes;
@@ -74,6 +75,7 @@ ProjectState carve_project(void* base, int64_t n) {
     s.rec0 = (f4*)(p + o); o += up(n * 16);
     s.rec1 = (f4*)(p + o); o += up(n * 16);
     s.rec2 = (f4*)(p + o); o += up(n * 16);
+    s.rect = (u2*)(p + o); o += up(n * 8);
     s.tiles = (uint32_t*)(p + o); o += up(n * 4);
     s.offsets = (uint32_t*)(p + o); o += up(n * 4);
     s.bytes = o;
@@ -173,6 +175,25 @@ __device__ __forceinline__ float dpp_row_sum(float v) {
     return v;
 }
 
+// Nine wave totals at once, step-interleaved so that no DPP instruction reads a register written by the previous
+// instruction (no s_nop padding between dependent VALU -> DPP pairs).
+__device__ __forceinline__ void wave_total9(float (&v)[9]) {
+#define DPP_STEP(ctrl, rmask)                                                                              \
+    _Pragma("unroll") for (int k = 0; k < 9; ++k) {                                                         \
+        const int x = __builtin_amdgcn_update_dpp(0, __float_as_int(v[k]), ctrl, rmask, 0xF, false);        \
+        v[k] += __int_as_float(x);                                                                          \
+    }
+    DPP_STEP(0xB1, 0xF)
+    DPP_STEP(0x4E, 0xF)
+    DPP_STEP(0x141, 0xF)
+    DPP_STEP(0x140, 0xF)
+    DPP_STEP(0x142, 0xA)
+    DPP_STEP(0x143, 0xC)
+#undef DPP_STEP
+#pragma unroll
+    for (int k = 0; k < 9; ++k) v[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[k]), 63));
+}
+
 __device__ __forceinline__ float wave_total(float v) {
     v = dpp_row_sum(v);
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
@@ -229,17 +250,17 @@ __global__ void finish_counts_kernel(const uint32_t* __restrict__ offsets, int64
 }
 
 // ---- K3 ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void emit_pairs_kernel(int64_t n, const f4* __restrict__ rec2, const uint32_t* __restrict__ tiles,
-                                                         const uint32_t* __restrict__ offsets, int tiles_x, int64_t n_pairs,
-                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+__global__ __launch_bounds__(256) void emit_pairs_kernel(int64_t n, const f4* __restrict__ rec2, const u2* __restrict__ rect,
+                                                         const uint32_t* __restrict__ tiles, const uint32_t* __restrict__ offsets,
+                                                         int tiles_x, int64_t n_pairs, uint64_t* __restrict__ keys,
+                                                         uint32_t* __restrict__ vals) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t nt = tiles[i];
     if (nt == 0) return;
-    const f4 r = rec2[i];
-    const uint32_t lo = f2u(r.z), hi = f2u(r.w);
-    const int tx0 = lo & 0xFFFF, ty0 = lo >> 16, tx1 = hi & 0xFFFF, ty1 = hi >> 16;
-    const uint64_t zbits = f2u(r.y);              // z > 0: the bit pattern orders like the value
+    const u2 r = rect[i];
+    const int tx0 = r.x & 0xFFFF, ty0 = r.x >> 16, tx1 = r.y & 0xFFFF, ty1 = r.y >> 16;
+    const uint64_t zbits = f2u(rec2[i].w);        // z > 0: the bit pattern orders like the value
     int64_t o = (int64_t)offsets[i] - nt;
     for (int ty = ty0; ty <= ty1; ++ty)
         for (int tx = tx0; tx <= tx1; ++tx) {
@@ -260,203 +281,230 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t n_pairs, const
     if (i == n_pairs - 1 || (uint32_t)(keys[i + 1] >> 32) != t) ranges[t].y = (uint32_t)(i + 1);
 }
 
-// ---- K6 ------------------------------------------------------------------------------------------
-// One wave64 per 16x16 tile.  Lane l owns column (l & 15) and rows (l >> 4) + 4k, k = 0..3.  The tile's
-// Gaussian list is staged through LDS 64 records at a time (SoA, broadcast reads, conflict-free).
+// ---- K6 / K7: rasterizer -----------------------------------------------------------------------------
+// One wave64 per HALF tile (16 x 8 pixels): lane l owns column (l & 15) and rows (l >> 4) and (l >> 4) + 4 of the
+// half, so the two pixels of a lane form a float2 and the arithmetic runs on packed fp32 (v_pk_fma_f32 ...).
+//
+// Staging = binning at wave granularity: the wave walks its tile's depth-sorted list 64 entries at a time; lane l
+// fetches entry l's record and tests the Gaussian's tight box {q <= chi} (ex, ey of the record) against the wave's
+// 16 x 8 pixel rectangle.  __ballot + mbcnt give every survivor its slot, in list order, and the survivors are
+// compacted into LDS.  The wave-wide inner loop then only visits Gaussians that can touch its pixels; a rejected
+// Gaussian costs one lane a few instructions instead of costing the whole wave an inner-loop iteration.  Skipping is
+// exact: a Gaussian whose box misses the rectangle has q > chi at every pixel there, i.e. alpha = 0 and T unchanged.
+//
+// Block -> region map: blocks b, b+8, ... share an XCD (round-robin dispatch).  Each XCD walks its own sequence of
+// 4 x 4-tile macro blocks (32 half-tile waves each), and macro block m belongs to XCD m % 8: neighbouring tiles share
+// an L2, while every XCD gets macro blocks from all over the image (a dense image centre does not land on one XCD).
+typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int BATCH = 64;
 
-struct TileBatch {
-    float u[BATCH], v[BATCH], a[BATCH], b2[BATCH], c[BATCH], o[BATCH], r[BATCH], g[BATCH], bl[BATCH];
+struct RasterStage {
+    f4 r0[BATCH];          // u, v, A11, 2*A12
+    f4 r1[BATCH];          // A22, opacity, r, g
+    float bl[BATCH];       // b
+    uint32_t id[BATCH];
 };
 
-__device__ __forceinline__ void stage_batch(TileBatch& s, int lane, int n, const uint32_t* __restrict__ ids, uint32_t base,
-                                            const f4* __restrict__ rec0, const f4* __restrict__ rec1, const f4* __restrict__ rec2,
-                                            uint32_t* s_id) {
-    if (lane < n) {
-        const uint32_t id = ids[base + lane];
-        const f4 q0 = rec0[id], q1 = rec1[id];
-        const float bl = rec2[id].x;
-        s.u[lane] = q0.x; s.v[lane] = q0.y; s.a[lane] = q0.z; s.b2[lane] = 2.0f * q0.w;
-        s.c[lane] = q1.x; s.o[lane] = q1.y; s.r[lane] = q1.z; s.g[lane] = q1.w; s.bl[lane] = bl;
-        if (s_id) s_id[lane] = id;
+__device__ __forceinline__ bool region_of_block(uint32_t b, int tiles_x, int tiles_y, int& tx, int& ty, int& half) {
+    const uint32_t macros_x = (uint32_t)(tiles_x + 3) >> 2;
+    const uint32_t xcd = b & 7u, j = b >> 3;
+    const uint32_t m = (j >> 5) * 8u + xcd, w = j & 31u;
+    tx = (int)((m % macros_x) * 4u + ((w >> 1) & 3u));
+    ty = (int)((m / macros_x) * 4u + (w >> 3));
+    half = (int)(w & 1u);
+    return tx < tiles_x && ty < tiles_y;
+}
+
+inline unsigned raster_grid(int tiles_x, int tiles_y) {
+    const unsigned macros = (unsigned)((tiles_x + 3) / 4) * (unsigned)((tiles_y + 3) / 4);
+    return (macros + 7u) / 8u * 8u * 32u;
+}
+
+// Cull + compact one chunk of the tile list into LDS.  Returns the number of survivors (wave-uniform).
+template <bool WITH_ID>
+__device__ __forceinline__ int stage_chunk(RasterStage& s, int lane, uint32_t base, uint32_t end, const uint32_t* __restrict__ ids,
+                                           const f4* __restrict__ rec0, const f4* __restrict__ rec1, const f4* __restrict__ rec2,
+                                           float x0, float x1, float y0, float y1) {
+    const uint32_t idx = base + lane;
+    bool pass = false;
+    uint32_t id = 0;
+    f4 q0, q1;
+    if (idx < end) {
+        id = ids[idx];
+        q0 = rec0[id];
+        q1 = rec1[id];
+        pass = (q0.x + q1.z >= x0) && (q0.x - q1.z <= x1) && (q0.y + q1.w >= y0) && (q0.y - q1.w <= y1);
     }
+    const unsigned long long mask = __ballot(pass);
+    if (mask == 0ull) return 0;
+    __syncthreads();       // previous chunk's LDS reads are done (single-wave block: orders LDS traffic only)
+    if (pass) {
+        const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        const f4 q2 = rec2[id];
+        s.r0[slot] = f4{q0.x, q0.y, q0.z, 2.0f * q0.w};
+        s.r1[slot] = f4{q1.x, q1.y, q2.x, q2.y};
+        s.bl[slot] = q2.z;
+        if (WITH_ID) s.id[slot] = id;
+    }
+    __syncthreads();
+    return (int)__popcll(mask);
 }
 
 __global__ __launch_bounds__(64) void raster_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ ids,
                                                             const f4* __restrict__ rec0, const f4* __restrict__ rec1,
-                                                            const f4* __restrict__ rec2, int n_tiles, int tiles_x, int H, int W,
+                                                            const f4* __restrict__ rec2, int tiles_x, int tiles_y, int H, int W,
                                                             float chi, float alpha_max, float alpha_cutoff,
                                                             float* __restrict__ image, float* __restrict__ accum) {
-    __shared__ TileBatch s;
+    __shared__ RasterStage s;
     const int lane = threadIdx.x;
-    const uint32_t tile = xcd_tile(blockIdx.x, (uint32_t)n_tiles);
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    int tx, ty, half;
+    if (!region_of_block(blockIdx.x, tiles_x, tiles_y, tx, ty, half)) return;
     const int px = tx * 16 + (lane & 15);
-    const int py0 = ty * 16 + (lane >> 4);
+    const int pya = ty * 16 + half * 8 + (lane >> 4), pyb = pya + 4;
+    const bool va = (px < W) && (pya < H), vb = (px < W) && (pyb < H);
     const float fpx = (float)px;
-    float T[4], C[4][3], fpy[4];
-    bool valid[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int py = py0 + 4 * k;
-        valid[k] = (px < W) && (py < H);
-        fpy[k] = (float)py;
-        T[k] = valid[k] ? 1.0f : 0.0f;
-        C[k][0] = C[k][1] = C[k][2] = 0.f;
-    }
-    const uint2 rg = ranges[tile];
-    bool all_done = false;
+    const v2f fpy = {(float)pya, (float)pyb};
+    v2f T = {va ? 1.0f : 0.0f, vb ? 1.0f : 0.0f};
+    v2f Cr = {0.f, 0.f}, Cg = {0.f, 0.f}, Cb = {0.f, 0.f};
+    const float x0 = (float)(tx * 16), x1 = x0 + 15.0f, y0 = (float)(ty * 16 + half * 8), y1 = y0 + 7.0f;
+    const uint2 rg = ranges[ty * tiles_x + tx];
+    bool all_done = !__any(va || vb);
     for (uint32_t base = rg.x; base < rg.y && !all_done; base += BATCH) {
-        const int n = min((uint32_t)BATCH, rg.y - base);
-        __syncthreads();
-        stage_batch(s, lane, n, ids, base, rec0, rec1, rec2, nullptr);
-        __syncthreads();
+        const int n = stage_chunk<false>(s, lane, base, rg.y, ids, rec0, rec1, rec2, x0, x1, y0, y1);
         for (int j = 0; j < n; ++j) {
-            const float du = fpx - s.u[j];
-            const float gv = s.v[j], ga = s.a[j], gb2 = s.b2[j], gc = s.c[j];
-            const float c0 = ga * du * du, c1 = gb2 * du;
-            float q[4];
-            bool any_in = false;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float dv = fpy[k] - gv;
-                q[k] = c0 + dv * (c1 + gc * dv);
-                any_in |= (q[k] <= chi);
-            }
-            if (!__any(any_in)) continue;
-            const float go = s.o[j], cr = s.r[j], cg = s.g[j], cb = s.bl[j];
-            bool done = true;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float gval = (q[k] <= chi) ? __expf(-0.5f * q[k]) : 0.0f;
-                float al = fminf(go * gval, alpha_max);
-                al = (al >= alpha_cutoff) ? al : 0.0f;
-                const bool alive = T[k] > 5e-5f;
-                const float w = alive ? al * T[k] : 0.0f;
-                C[k][0] += w * cr; C[k][1] += w * cg; C[k][2] += w * cb;
-                T[k] *= (1.0f - al);
-                done &= !(T[k] > 5e-5f);
-            }
-            if (__all(done)) { all_done = true; break; }
+            const f4 a = s.r0[j], b = s.r1[j];
+            const float du = fpx - a.x;
+            const v2f dv = fpy - a.y;
+            const float c0 = a.z * du * du, c1 = a.w * du;
+            const v2f q = c0 + dv * (c1 + b.x * dv);
+            const bool i0 = q.x <= chi, i1 = q.y <= chi;
+            if (!__any(i0 || i1)) continue;
+            const float cbl = s.bl[j];
+            v2f g;
+            g.x = i0 ? __expf(-0.5f * q.x) : 0.0f;
+            g.y = i1 ? __expf(-0.5f * q.y) : 0.0f;
+            v2f al = b.y * g;
+            al.x = fminf(al.x, alpha_max); al.y = fminf(al.y, alpha_max);
+            al.x = (al.x >= alpha_cutoff) ? al.x : 0.0f; al.y = (al.y >= alpha_cutoff) ? al.y : 0.0f;
+            v2f w = al * T;
+            w.x = (T.x > 5e-5f) ? w.x : 0.0f; w.y = (T.y > 5e-5f) ? w.y : 0.0f;
+            Cr += w * b.z; Cg += w * b.w; Cb += w * cbl;
+            T = T - al * T;
+            if (!__any(T.x > 5e-5f || T.y > 5e-5f)) { all_done = true; break; }
         }
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (valid[k]) {
-            const int64_t o = ((int64_t)(py0 + 4 * k) * W + px) * 3;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                image[o + c] = fminf(fmaxf(C[k][c], 0.0f), 1.0f);
-                if (accum) accum[o + c] = C[k][c];
-            }
-        }
+    if (va) {
+        const int64_t o = ((int64_t)pya * W + px) * 3;
+        image[o + 0] = fminf(fmaxf(Cr.x, 0.0f), 1.0f); image[o + 1] = fminf(fmaxf(Cg.x, 0.0f), 1.0f);
+        image[o + 2] = fminf(fmaxf(Cb.x, 0.0f), 1.0f);
+        if (accum) { accum[o + 0] = Cr.x; accum[o + 1] = Cg.x; accum[o + 2] = Cb.x; }
+    }
+    if (vb) {
+        const int64_t o = ((int64_t)pyb * W + px) * 3;
+        image[o + 0] = fminf(fmaxf(Cr.y, 0.0f), 1.0f); image[o + 1] = fminf(fmaxf(Cg.y, 0.0f), 1.0f);
+        image[o + 2] = fminf(fmaxf(Cb.y, 0.0f), 1.0f);
+        if (accum) { accum[o + 0] = Cr.y; accum[o + 1] = Cg.y; accum[o + 2] = Cb.y; }
     }
 }
 
-// ---- K7 ------------------------------------------------------------------------------------------
-// Same front-to-back traversal as K6 (identical T_i and alive decisions).  For pixel p and Gaussian i:
+// K7: same traversal as K6 (identical T_i and alive decisions).  For pixel p and Gaussian i:
 //   d alpha_i = alive_i T_i (c_i . Gc) - (sum_{k>i} w_k (c_k . Gc)) / (1 - alpha_i),
-// the suffix sum being (total - running prefix), total = Gc . C_unclamped.  Nine per-Gaussian sums are reduced
-// over the wave with DPP and added to grad2d[id][0..8] by lanes 0..8 (one 36-byte atomic request per pair).
+// the suffix sum being (total - running prefix), total = Gc . C_unclamped, Gc = dL/dO masked by the output clamp.
+// Nine per-Gaussian sums are reduced over the wave with DPP and added to grad2d[id][0..8] by lanes 0..8 (one 36-byte
+// atomic request per (half tile, Gaussian) pair that actually touched a pixel).
 __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ ids,
                                                              const f4* __restrict__ rec0, const f4* __restrict__ rec1,
-                                                             const f4* __restrict__ rec2, int n_tiles, int tiles_x, int H, int W,
+                                                             const f4* __restrict__ rec2, int tiles_x, int tiles_y, int H, int W,
                                                              float chi, float alpha_max, float alpha_cutoff,
                                                              const float* __restrict__ accum, const float* __restrict__ gimg,
                                                              float* __restrict__ grad2d) {
-    __shared__ TileBatch s;
-    __shared__ uint32_t s_id[BATCH];
+    __shared__ RasterStage s;
     const int lane = threadIdx.x;
-    const uint32_t tile = xcd_tile(blockIdx.x, (uint32_t)n_tiles);
-    const uint2 rg = ranges[tile];
+    int tx, ty, half;
+    if (!region_of_block(blockIdx.x, tiles_x, tiles_y, tx, ty, half)) return;
+    const uint2 rg = ranges[ty * tiles_x + tx];
     if (rg.x >= rg.y) return;
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int px = tx * 16 + (lane & 15);
-    const int py0 = ty * 16 + (lane >> 4);
+    const int pya = ty * 16 + half * 8 + (lane >> 4), pyb = pya + 4;
+    const bool va = (px < W) && (pya < H), vb = (px < W) && (pyb < H);
     const float fpx = (float)px;
-    float T[4], fpy[4], G[4][3], suffix[4];
+    const v2f fpy = {(float)pya, (float)pyb};
+    v2f T = {va ? 1.0f : 0.0f, vb ? 1.0f : 0.0f};
+    v2f Gr = {0.f, 0.f}, Gg = {0.f, 0.f}, Gb = {0.f, 0.f}, suffix = {0.f, 0.f};
+    {
+        float g[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, sfx[2] = {0.f, 0.f};
+        const bool vv[2] = {va, vb};
+        const int py[2] = {pya, pyb};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int py = py0 + 4 * k;
-        const bool valid = (px < W) && (py < H);
-        fpy[k] = (float)py;
-        T[k] = valid ? 1.0f : 0.0f;
-        suffix[k] = 0.f;
+        for (int k = 0; k < 2; ++k) {
+            if (vv[k]) {
+                const int64_t o = ((int64_t)py[k] * W + px) * 3;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) G[k][c] = 0.f;
-        if (valid) {
-            const int64_t o = ((int64_t)py * W + px) * 3;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float cu = accum[o + c];
-                // clamp(C, 0, 1) passes the gradient where 0 <= C <= 1 (render.py:410)
-                const float gv = (cu >= 0.0f && cu <= 1.0f) ? gimg[o + c] : 0.0f;
-                G[k][c] = gv;
-                suffix[k] += gv * cu;
+                for (int c = 0; c < 3; ++c) {
+                    const float cu = accum[o + c];
+                    // clamp(C, 0, 1) passes the gradient where 0 <= C <= 1 (render.py:410)
+                    const float gv = (cu >= 0.0f && cu <= 1.0f) ? gimg[o + c] : 0.0f;
+                    g[k][c] = gv;
+                    sfx[k] += gv * cu;
+                }
             }
         }
+        Gr = v2f{g[0][0], g[1][0]}; Gg = v2f{g[0][1], g[1][1]}; Gb = v2f{g[0][2], g[1][2]};
+        suffix = v2f{sfx[0], sfx[1]};
     }
-    bool all_done = false;
+    const float x0 = (float)(tx * 16), x1 = x0 + 15.0f, y0 = (float)(ty * 16 + half * 8), y1 = y0 + 7.0f;
+    bool all_done = !__any(va || vb);
     for (uint32_t base = rg.x; base < rg.y && !all_done; base += BATCH) {
-        const int n = min((uint32_t)BATCH, rg.y - base);
-        __syncthreads();
-        stage_batch(s, lane, n, ids, base, rec0, rec1, rec2, s_id);
-        __syncthreads();
+        const int n = stage_chunk<true>(s, lane, base, rg.y, ids, rec0, rec1, rec2, x0, x1, y0, y1);
         for (int j = 0; j < n; ++j) {
-            const float du = fpx - s.u[j];
-            const float gv = s.v[j], ga = s.a[j], gb2 = s.b2[j], gc = s.c[j];
-            const float c0 = ga * du * du, c1 = gb2 * du;
-            float q[4], dv[4];
-            bool any_in = false;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                dv[k] = fpy[k] - gv;
-                q[k] = c0 + dv[k] * (c1 + gc * dv[k]);
-                any_in |= (q[k] <= chi);
-            }
-            if (!__any(any_in)) continue;
-            const float go = s.o[j], cr = s.r[j], cg = s.g[j], cb = s.bl[j];
-            float a_u = 0.f, a_v = 0.f, a_A11 = 0.f, a_A12 = 0.f, a_A22 = 0.f, a_o = 0.f, a_r = 0.f, a_g = 0.f, a_b = 0.f;
-            bool done = true, touched = false;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float gval = (q[k] <= chi) ? __expf(-0.5f * q[k]) : 0.0f;
-                const float og = go * gval;
-                float al = fminf(og, alpha_max);
-                al = (al >= alpha_cutoff) ? al : 0.0f;
-                const bool alive = T[k] > 5e-5f;
-                if (alive && al > 0.0f) {
-                    touched = true;
-                    const float w = al * T[k];
-                    const float sdot = cr * G[k][0] + cg * G[k][1] + cb * G[k][2];
-                    a_r += w * G[k][0]; a_g += w * G[k][1]; a_b += w * G[k][2];
-                    suffix[k] -= w * sdot;                                   // now sum over k > i
-                    const float dal = T[k] * sdot - suffix[k] / (1.0f - al);
-                    if (og <= alpha_max) {                                   // clamp_max passes the gradient (render.py:372)
-                        a_o += dal * gval;
-                        const float dq = -0.5f * gval * go * dal;            // q <= chi here (gval > 0)
-                        const float du2 = du * dq, dv2 = dv[k] * dq;
-                        a_A11 += du * du2; a_A12 += 2.0f * du * dv2; a_A22 += dv[k] * dv2;
-                        a_u -= (2.0f * ga * du + gb2 * dv[k]) * dq;
-                        a_v -= (gb2 * du + 2.0f * gc * dv[k]) * dq;
-                    }
-                }
-                T[k] *= (1.0f - al);
-                done &= !(T[k] > 5e-5f);
-            }
-            if (__any(touched)) {
-                const float t0 = wave_total(a_u), t1 = wave_total(a_v), t2 = wave_total(a_A11), t3 = wave_total(a_A12),
-                            t4 = wave_total(a_A22), t5 = wave_total(a_o), t6 = wave_total(a_r), t7 = wave_total(a_g),
-                            t8 = wave_total(a_b);
+            const f4 a = s.r0[j], b = s.r1[j];
+            const float du = fpx - a.x;
+            const v2f dv = fpy - a.y;
+            const float c0 = a.z * du * du, c1 = a.w * du;
+            const v2f q = c0 + dv * (c1 + b.x * dv);
+            const bool i0 = q.x <= chi, i1 = q.y <= chi;
+            if (!__any(i0 || i1)) continue;
+            const float cbl = s.bl[j], go = b.y;
+            v2f g;
+            g.x = i0 ? __expf(-0.5f * q.x) : 0.0f;
+            g.y = i1 ? __expf(-0.5f * q.y) : 0.0f;
+            const v2f og = go * g;
+            v2f al;
+            al.x = fminf(og.x, alpha_max); al.y = fminf(og.y, alpha_max);
+            al.x = (al.x >= alpha_cutoff) ? al.x : 0.0f; al.y = (al.y >= alpha_cutoff) ? al.y : 0.0f;
+            const bool act0 = (T.x > 5e-5f) && (al.x > 0.0f), act1 = (T.y > 5e-5f) && (al.y > 0.0f);
+            if (__any(act0 || act1)) {
+                v2f w = al * T;
+                w.x = act0 ? w.x : 0.0f; w.y = act1 ? w.y : 0.0f;
+                const v2f sdot = b.z * Gr + b.w * Gg + cbl * Gb;
+                const v2f ar = w * Gr, ag = w * Gg, ab = w * Gb;
+                suffix -= w * sdot;                                            // now the sum over k > i
+                v2f om = 1.0f - al;
+                om.x = __builtin_amdgcn_rcpf(om.x); om.y = __builtin_amdgcn_rcpf(om.y);   // 1 - alpha >= 0.01
+                v2f dal = T * sdot - suffix * om;
+                // clamp_max passes the gradient where o g <= alpha_max (render.py:372); alpha > 0 implies q <= chi
+                dal.x = (act0 && og.x <= alpha_max) ? dal.x : 0.0f;
+                dal.y = (act1 && og.y <= alpha_max) ? dal.y : 0.0f;
+                const v2f ao = dal * g;
+                const v2f dq = (-0.5f * go) * (g * dal);
+                const v2f dvq = dv * dq;
+                const float dqs = dq.x + dq.y, dvqs = dvq.x + dvq.y;
+                const float t_A11 = du * du * dqs;
+                const float t_A12 = 2.0f * du * dvqs;
+                const v2f aA22 = dv * dvq;
+                const float t_u = -(2.0f * a.z * du * dqs + a.w * dvqs);
+                const float t_v = -(a.w * du * dqs + 2.0f * b.x * dvqs);
+                float r[9] = {t_u, t_v, t_A11, t_A12, aA22.x + aA22.y, ao.x + ao.y, ar.x + ar.y, ag.x + ag.y, ab.x + ab.y};
+                wave_total9(r);
                 if (lane < 9) {
-                    float mine = t0;
-                    mine = lane == 1 ? t1 : mine; mine = lane == 2 ? t2 : mine; mine = lane == 3 ? t3 : mine;
-                    mine = lane == 4 ? t4 : mine; mine = lane == 5 ? t5 : mine; mine = lane == 6 ? t6 : mine;
-                    mine = lane == 7 ? t7 : mine; mine = lane == 8 ? t8 : mine;
-                    atomicAdd(&grad2d[(int64_t)s_id[j] * 16 + lane], mine);
+                    float mine = r[0];
+#pragma unroll
+                    for (int k = 1; k < 9; ++k) mine = (lane == k) ? r[k] : mine;
+                    atomicAdd(&grad2d[(int64_t)s.id[j] * 16 + lane], mine);
                 }
             }
-            if (__all(done)) { all_done = true; break; }
+            T = T - al * T;
+            if (!__any(T.x > 5e-5f || T.y > 5e-5f)) { all_done = true; break; }
         }
     }
 }
@@ -559,7 +607,7 @@ int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_vie
     hipLaunchKernelGGL(camera_kernel, dim3(1), dim3(64), 0, st, c2w, ps.cam, ps.counts);
     LAUNCH_CHECK("camera_kernel");
     if (n > 0) {
-        Records out{ps.rec0, ps.rec1, ps.rec2, ps.tiles};
+        Records out{ps.rec0, ps.rec1, ps.rec2, ps.rect, ps.tiles};
         if (fused)
             hipLaunchKernelGGL(project_kernel<true>, dim3(blocks256(n)), dim3(256), 0, st, *g, ps.cam, vk, out, ps.counts);
         else
@@ -590,8 +638,8 @@ int gsplat_bin(int64_t n, int64_t n_pairs, const gsplat_view* v, const void* pro
     if (n_pairs == 0 || n == 0) return GSPLAT_OK;
     BinScratch sc = carve_bin_scratch(scratch, n_pairs);
     if (!scratch || sc.bytes > scratch_bytes) return fail(GSPLAT_ERR_WORKSPACE, "bin scratch too small");
-    hipLaunchKernelGGL(emit_pairs_kernel, dim3(blocks256(n)), dim3(256), 0, st, n, ps.rec2, ps.tiles, ps.offsets, vk.tiles_x, n_pairs,
-                       sc.keys_in, sc.vals_in);
+    hipLaunchKernelGGL(emit_pairs_kernel, dim3(blocks256(n)), dim3(256), 0, st, n, ps.rec2, ps.rect, ps.tiles, ps.offsets, vk.tiles_x,
+                       n_pairs, sc.keys_in, sc.vals_in);
     LAUNCH_CHECK("emit_pairs_kernel");
     unsigned tile_bits = 1;
     while ((1LL << tile_bits) < nt) ++tile_bits;
@@ -613,8 +661,9 @@ int gsplat_rasterize_forward(int64_t n, int64_t n_pairs, const gsplat_view* v, c
     const int64_t nt = (int64_t)vk.tiles_x * vk.tiles_y;
     ProjectState ps = carve_project((void*)project_state, n > 0 ? n : 1);
     BinState bs = carve_bin((void*)bin_state, n_pairs, nt);
-    hipLaunchKernelGGL(raster_forward_kernel, dim3((unsigned)nt), dim3(64), 0, st, bs.ranges, bs.sorted_ids, ps.rec0, ps.rec1, ps.rec2,
-                       (int)nt, vk.tiles_x, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, image, accum);
+    hipLaunchKernelGGL(raster_forward_kernel, dim3(raster_grid(vk.tiles_x, vk.tiles_y)), dim3(64), 0, st, bs.ranges, bs.sorted_ids,
+                       ps.rec0, ps.rec1, ps.rec2, vk.tiles_x, vk.tiles_y, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, image,
+                       accum);
     LAUNCH_CHECK("raster_forward_kernel");
     return GSPLAT_OK;
 }
@@ -631,8 +680,9 @@ int gsplat_rasterize_backward(int64_t n, int64_t n_pairs, const gsplat_view* v, 
     BinState bs = carve_bin((void*)bin_state, n_pairs, nt);
     HIP_TRY(hipMemsetAsync(grad2d, 0, (size_t)(n > 0 ? n : 0) * 16 * sizeof(float), st));
     if (n == 0 || n_pairs == 0) return GSPLAT_OK;
-    hipLaunchKernelGGL(raster_backward_kernel, dim3((unsigned)nt), dim3(64), 0, st, bs.ranges, bs.sorted_ids, ps.rec0, ps.rec1, ps.rec2,
-                       (int)nt, vk.tiles_x, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, accum, grad_image, grad2d);
+    hipLaunchKernelGGL(raster_backward_kernel, dim3(raster_grid(vk.tiles_x, vk.tiles_y)), dim3(64), 0, st, bs.ranges, bs.sorted_ids,
+                       ps.rec0, ps.rec1, ps.rec2, vk.tiles_x, vk.tiles_y, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, accum,
+                       grad_image, grad2d);
     LAUNCH_CHECK("raster_backward_kernel");
     return GSPLAT_OK;
 }

@@ -45,11 +45,13 @@ def _project(hm, d, arrs, fused=True, color=None, sigma=None):
     n = len(arrs["pos"])
     view = abi.make_view(*util.cam_args(d), **d["kwargs"])
     rec = [np.zeros((n, 4), np.float32) for _ in range(3)]
+    rec.append(np.zeros((n, 2), np.uint32))     # rec[3] = tile rectangle
     tiles = np.zeros(n, np.uint32)
     vis = np.zeros(n, np.int32)
     g = _gaussians(arrs, fused, color, sigma)
     c2w = np.ascontiguousarray(d["c2w"], np.float32)
-    hm.hm_project(C.byref(g), _ptr(c2w), C.byref(view), _ptr(rec[0]), _ptr(rec[1]), _ptr(rec[2]), _ptr(tiles), _ptr(vis))
+    hm.hm_project(C.byref(g), _ptr(c2w), C.byref(view), _ptr(rec[0]), _ptr(rec[1]), _ptr(rec[2]), _ptr(rec[3]), _ptr(tiles),
+                  _ptr(vis))
     return rec, tiles, vis, view, g, c2w
 
 
@@ -73,9 +75,16 @@ def test_forward_records_vs_reference_intermediates(hm, name):
     cond = (ev[:, 1] / ev[:, 0])[:, None]
     assert (np.abs(mine - ref) <= (2e-6 * cond + 1e-5) * scale).all()
     assert np.abs(rec[1][ids, 1] - d["im_opacity"]).max() < 1e-6
-    rgb = np.stack([rec[1][ids, 2], rec[1][ids, 3], rec[2][ids, 0]], 1)
+    rgb = rec[2][ids, :3]
     assert np.abs(rgb - d["im_color"]).max() < 2e-6
-    rl, rh = rec[2][ids, 2].copy().view(np.uint32), rec[2][ids, 3].copy().view(np.uint32)
+    # tight extents of {q <= chi}: must contain every pixel offset with q <= chi (checked on the reference conic)
+    chi = d["kwargs"].get("chi_square_clip", 6.25)
+    ex, ey = rec[1][ids, 2].astype(np.float64), rec[1][ids, 3].astype(np.float64)
+    det = ref[:, 0] * ref[:, 2] - ref[:, 1] ** 2
+    ok = det > 0
+    assert (ex[ok] >= np.sqrt(chi * ref[ok, 2] / det[ok]) * (1 - 1e-3 * np.minimum(cond[ok, 0], 50))).all()
+    assert (ey[ok] >= np.sqrt(chi * ref[ok, 0] / det[ok]) * (1 - 1e-3 * np.minimum(cond[ok, 0], 50))).all()
+    rl, rh = rec[3][ids, 0], rec[3][ids, 1]
     rect = np.stack([rl & 0xFFFF, rl >> 16, rh & 0xFFFF, rh >> 16], 1).astype(np.int32)
     # ceil() in the radius is a discontinuity: a 1-ulp eigenvalue difference can move an AABB edge by one pixel
     # (harmless: pixels with q <= chi_square_clip always lie inside the smaller box), so allow a few mismatches
