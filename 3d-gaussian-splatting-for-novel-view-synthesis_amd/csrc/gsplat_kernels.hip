@@ -85,6 +85,9 @@ ProjectState carve_project(void* base, int64_t n) {
 struct BinState {
     uint32_t* sorted_ids;    // [P] Gaussian ids in (tile, depth, id) order
     uint2* ranges;           // [tiles] start, end
+    uint32_t* order_fwd;     // [tiles] launch order of the forward raster (longest list first)
+    uint32_t* order_bwd;     // [tiles] launch order of the backward raster (most visited first)
+    uint32_t* visited;       // [2 * tiles] Gaussians the forward visited per half tile
     int64_t bytes;
 };
 
@@ -94,6 +97,9 @@ BinState carve_bin(void* base, int64_t n_pairs, int64_t n_tiles) {
     int64_t o = 0;
     s.sorted_ids = (uint32_t*)(p + o); o += up((n_pairs > 0 ? n_pairs : 1) * 4);
     s.ranges = (uint2*)(p + o); o += up(n_tiles * 8);
+    s.order_fwd = (uint32_t*)(p + o); o += up(n_tiles * 4);
+    s.order_bwd = (uint32_t*)(p + o); o += up(n_tiles * 4);
+    s.visited = (uint32_t*)(p + o); o += up(n_tiles * 8);
     s.bytes = o;
     return s;
 }
@@ -281,6 +287,39 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t n_pairs, const
     if (i == n_pairs - 1 || (uint32_t)(keys[i + 1] >> 32) != t) ranges[t].y = (uint32_t)(i + 1);
 }
 
+// ---- K5b: launch order ------------------------------------------------------------------------------
+// Longest-processing-time-first order of the tiles (descending work, 1/8-octave buckets).  The raster kernels are
+// tail-bound: a few dense tiles take 5x the mean, so they must start first (and get issue priority, see s_setprio).
+// work(t) = list length (forward) or the number of Gaussians the forward actually visited in the tile (backward).
+__device__ __forceinline__ uint32_t work_bucket(uint32_t w) {
+    if (w < 8u) return w;
+    const uint32_t e = 31u - (uint32_t)__clz((int)w);
+    return (e - 2u) * 8u + ((w >> (e - 3u)) & 7u);          // <= 239
+}
+
+__global__ __launch_bounds__(1024) void order_tiles_kernel(int n_tiles, const uint2* __restrict__ ranges,
+                                                           const uint32_t* __restrict__ visited, uint32_t* __restrict__ order) {
+    __shared__ uint32_t hist[256], cursor[256];
+    const int tid = threadIdx.x;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (int t = tid; t < n_tiles; t += 1024) {
+        const uint32_t w = visited ? visited[2 * t] + visited[2 * t + 1] : ranges[t].y - ranges[t].x;
+        atomicAdd(&hist[work_bucket(w)], 1u);
+    }
+    __syncthreads();
+    if (tid < 256) {
+        uint32_t above = 0;
+        for (int k = 255; k > tid; --k) above += hist[k];
+        cursor[tid] = above;
+    }
+    __syncthreads();
+    for (int t = tid; t < n_tiles; t += 1024) {
+        const uint32_t w = visited ? visited[2 * t] + visited[2 * t + 1] : ranges[t].y - ranges[t].x;
+        order[atomicAdd(&cursor[work_bucket(w)], 1u)] = (uint32_t)t;
+    }
+}
+
 // ---- K6 / K7: rasterizer -----------------------------------------------------------------------------
 // One wave64 per HALF tile (16 x 8 pixels): lane l owns column (l & 15) and rows (l >> 4) and (l >> 4) + 4 of the
 // half, so the two pixels of a lane form a float2 and the arithmetic runs on packed fp32 (v_pk_fma_f32 ...).
@@ -291,74 +330,96 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t n_pairs, const
 // compacted into LDS.  The wave-wide inner loop then only visits Gaussians that can touch its pixels; a rejected
 // Gaussian costs one lane a few instructions instead of costing the whole wave an inner-loop iteration.  Skipping is
 // exact: a Gaussian whose box misses the rectangle has q > chi at every pixel there, i.e. alpha = 0 and T unchanged.
+// The next chunk's records are fetched while the current chunk's survivors are composited.
 //
-// Block -> region map: blocks b, b+8, ... share an XCD (round-robin dispatch).  Each XCD walks its own sequence of
-// 4 x 4-tile macro blocks (32 half-tile waves each), and macro block m belongs to XCD m % 8: neighbouring tiles share
-// an L2, while every XCD gets macro blocks from all over the image (a dense image centre does not land on one XCD).
+// Launch order: block b takes tile order[b >> 1], half b & 1, with `order` from order_tiles_kernel (heaviest first),
+// and the first blocks raise their wave priority so that a dense tile is not slowed down by light co-resident waves.
 typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int BATCH = 64;
 
+// Diagnostics (tools/raster_stats.py): when a buffer is registered with gsplat_debug_set_stats(), every raster wave
+// writes {list length, chunks staged, survivors visited, shader cycles} for its region.  Never set in normal use.
+struct WaveStats { uint32_t list_len, chunks, visited, cycles; };
+WaveStats* g_stats_fwd = nullptr;
+WaveStats* g_stats_bwd = nullptr;
+
 struct RasterStage {
-    f4 r0[BATCH];          // u, v, A11, 2*A12
-    f4 r1[BATCH];          // A22, opacity, r, g
-    float bl[BATCH];       // b
-    uint32_t id[BATCH];
+    f4 r0[BATCH + 2];      // u, v, A11, 2*A12        (+2: null records that pad an odd survivor count)
+    f4 r1[BATCH + 2];      // A22, opacity, r, g
+    float bl[BATCH + 2];   // b
+    uint32_t id[BATCH + 2];
 };
 
-__device__ __forceinline__ bool region_of_block(uint32_t b, int tiles_x, int tiles_y, int& tx, int& ty, int& half) {
-    const uint32_t macros_x = (uint32_t)(tiles_x + 3) >> 2;
-    const uint32_t xcd = b & 7u, j = b >> 3;
-    const uint32_t m = (j >> 5) * 8u + xcd, w = j & 31u;
-    tx = (int)((m % macros_x) * 4u + ((w >> 1) & 3u));
-    ty = (int)((m / macros_x) * 4u + (w >> 3));
-    half = (int)(w & 1u);
-    return tx < tiles_x && ty < tiles_y;
-}
+struct Candidate {         // one list entry held by one lane between fetch and test
+    f4 q0, q1, q2;
+    uint32_t id;
+    bool valid;
+};
 
-inline unsigned raster_grid(int tiles_x, int tiles_y) {
-    const unsigned macros = (unsigned)((tiles_x + 3) / 4) * (unsigned)((tiles_y + 3) / 4);
-    return (macros + 7u) / 8u * 8u * 32u;
-}
-
-// Cull + compact one chunk of the tile list into LDS.  Returns the number of survivors (wave-uniform).
-template <bool WITH_ID>
-__device__ __forceinline__ int stage_chunk(RasterStage& s, int lane, uint32_t base, uint32_t end, const uint32_t* __restrict__ ids,
-                                           const f4* __restrict__ rec0, const f4* __restrict__ rec1, const f4* __restrict__ rec2,
-                                           float x0, float x1, float y0, float y1) {
+__device__ __forceinline__ Candidate fetch_candidate(int lane, uint32_t base, uint32_t end, const uint32_t* __restrict__ ids,
+                                                     const f4* __restrict__ rec0, const f4* __restrict__ rec1,
+                                                     const f4* __restrict__ rec2) {
+    Candidate c;
     const uint32_t idx = base + lane;
-    bool pass = false;
-    uint32_t id = 0;
-    f4 q0, q1;
-    if (idx < end) {
-        id = ids[idx];
-        q0 = rec0[id];
-        q1 = rec1[id];
-        pass = (q0.x + q1.z >= x0) && (q0.x - q1.z <= x1) && (q0.y + q1.w >= y0) && (q0.y - q1.w <= y1);
+    c.valid = idx < end;
+    c.id = 0;
+    c.q0 = c.q1 = c.q2 = f4{0.f, 0.f, 0.f, 0.f};
+    if (c.valid) {
+        c.id = ids[idx];
+        c.q0 = rec0[c.id];
+        c.q1 = rec1[c.id];
+        c.q2 = rec2[c.id];
     }
+    return c;
+}
+
+// Cull + compact the fetched candidates into LDS, padded to an even count.  Returns the survivor count (uniform).
+template <bool WITH_ID>
+__device__ __forceinline__ int compact_candidates(RasterStage& s, const Candidate& c, float x0, float x1, float y0, float y1) {
+    const bool pass = c.valid && (c.q0.x + c.q1.z >= x0) && (c.q0.x - c.q1.z <= x1) && (c.q0.y + c.q1.w >= y0) &&
+                      (c.q0.y - c.q1.w <= y1);
     const unsigned long long mask = __ballot(pass);
     if (mask == 0ull) return 0;
+    const int n = (int)__popcll(mask);
     __syncthreads();       // previous chunk's LDS reads are done (single-wave block: orders LDS traffic only)
     if (pass) {
         const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        const f4 q2 = rec2[id];
-        s.r0[slot] = f4{q0.x, q0.y, q0.z, 2.0f * q0.w};
-        s.r1[slot] = f4{q1.x, q1.y, q2.x, q2.y};
-        s.bl[slot] = q2.z;
-        if (WITH_ID) s.id[slot] = id;
+        s.r0[slot] = f4{c.q0.x, c.q0.y, c.q0.z, 2.0f * c.q0.w};
+        s.r1[slot] = f4{c.q1.x, c.q1.y, c.q2.x, c.q2.y};
+        s.bl[slot] = c.q2.z;
+        if (WITH_ID) s.id[slot] = c.id;
+    }
+    if (threadIdx.x == 0) {                                   // null record: opacity 0 -> alpha 0, T unchanged
+        s.r0[n] = f4{0.f, 0.f, 0.f, 0.f};
+        s.r1[n] = f4{0.f, 0.f, 0.f, 0.f};
+        s.bl[n] = 0.f;
     }
     __syncthreads();
-    return (int)__popcll(mask);
+    return n;
+}
+
+__device__ __forceinline__ int launch_priority(uint32_t b, uint32_t grid) {
+    return b * 64u < grid ? 3 : (b * 16u < grid ? 2 : (b * 4u < grid ? 1 : 0));
 }
 
 __global__ __launch_bounds__(64) void raster_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ ids,
                                                             const f4* __restrict__ rec0, const f4* __restrict__ rec1,
-                                                            const f4* __restrict__ rec2, int tiles_x, int tiles_y, int H, int W,
-                                                            float chi, float alpha_max, float alpha_cutoff,
-                                                            float* __restrict__ image, float* __restrict__ accum) {
+                                                            const f4* __restrict__ rec2, const uint32_t* __restrict__ order,
+                                                            int tiles_x, int H, int W, float chi, float alpha_max,
+                                                            float alpha_cutoff, float* __restrict__ image,
+                                                            float* __restrict__ accum, uint32_t* __restrict__ visited,
+                                                            WaveStats* __restrict__ stats) {
     __shared__ RasterStage s;
     const int lane = threadIdx.x;
-    int tx, ty, half;
-    if (!region_of_block(blockIdx.x, tiles_x, tiles_y, tx, ty, half)) return;
+    const uint32_t tile = order[blockIdx.x >> 1];
+    const int half = blockIdx.x & 1;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int prio = launch_priority(blockIdx.x, gridDim.x);
+    if (prio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+    const unsigned long long t_begin = stats ? __builtin_amdgcn_s_memtime() : 0ull;
+    uint32_t st_chunks = 0, st_visited = 0;
     const int px = tx * 16 + (lane & 15);
     const int pya = ty * 16 + half * 8 + (lane >> 4), pyb = pya + 4;
     const bool va = (px < W) && (pya < H), vb = (px < W) && (pyb < H);
@@ -367,32 +428,49 @@ __global__ __launch_bounds__(64) void raster_forward_kernel(const uint2* __restr
     v2f T = {va ? 1.0f : 0.0f, vb ? 1.0f : 0.0f};
     v2f Cr = {0.f, 0.f}, Cg = {0.f, 0.f}, Cb = {0.f, 0.f};
     const float x0 = (float)(tx * 16), x1 = x0 + 15.0f, y0 = (float)(ty * 16 + half * 8), y1 = y0 + 7.0f;
-    const uint2 rg = ranges[ty * tiles_x + tx];
-    bool all_done = !__any(va || vb);
-    for (uint32_t base = rg.x; base < rg.y && !all_done; base += BATCH) {
-        const int n = stage_chunk<false>(s, lane, base, rg.y, ids, rec0, rec1, rec2, x0, x1, y0, y1);
-        for (int j = 0; j < n; ++j) {
-            const f4 a = s.r0[j], b = s.r1[j];
-            const float du = fpx - a.x;
-            const v2f dv = fpy - a.y;
-            const float c0 = a.z * du * du, c1 = a.w * du;
-            const v2f q = c0 + dv * (c1 + b.x * dv);
-            const bool i0 = q.x <= chi, i1 = q.y <= chi;
-            if (!__any(i0 || i1)) continue;
-            const float cbl = s.bl[j];
-            v2f g;
-            g.x = i0 ? __expf(-0.5f * q.x) : 0.0f;
-            g.y = i1 ? __expf(-0.5f * q.y) : 0.0f;
-            v2f al = b.y * g;
-            al.x = fminf(al.x, alpha_max); al.y = fminf(al.y, alpha_max);
-            al.x = (al.x >= alpha_cutoff) ? al.x : 0.0f; al.y = (al.y >= alpha_cutoff) ? al.y : 0.0f;
-            v2f w = al * T;
-            w.x = (T.x > 5e-5f) ? w.x : 0.0f; w.y = (T.y > 5e-5f) ? w.y : 0.0f;
-            Cr += w * b.z; Cg += w * b.w; Cb += w * cbl;
-            T = T - al * T;
-            if (!__any(T.x > 5e-5f || T.y > 5e-5f)) { all_done = true; break; }
+    const uint2 rg = ranges[tile];
+    bool alive_any = __any(va || vb);
+    uint32_t base = rg.x;
+    Candidate cand;
+    if (alive_any && base < rg.y) cand = fetch_candidate(lane, base, rg.y, ids, rec0, rec1, rec2);
+    while (alive_any && base < rg.y) {
+        const int n = compact_candidates<false>(s, cand, x0, x1, y0, y1);
+        base += BATCH;
+        if (base < rg.y) cand = fetch_candidate(lane, base, rg.y, ids, rec0, rec1, rec2);   // in flight during the loop below
+        ++st_chunks;
+        st_visited += (uint32_t)n;
+        for (int j = 0; j < n; j += 2) {
+            const f4 a0 = s.r0[j], b0 = s.r1[j], a1 = s.r0[j + 1], b1 = s.r1[j + 1];
+            const float du0 = fpx - a0.x, du1 = fpx - a1.x;
+            const v2f dv0 = fpy - a0.y, dv1 = fpy - a1.y;
+            const v2f q0 = (a0.z * du0 * du0) + dv0 * ((a0.w * du0) + b0.x * dv0);
+            const v2f q1 = (a1.z * du1 * du1) + dv1 * ((a1.w * du1) + b1.x * dv1);
+            const bool i00 = q0.x <= chi, i01 = q0.y <= chi, i10 = q1.x <= chi, i11 = q1.y <= chi;
+            if (__any(i00 || i01 || i10 || i11)) {
+                const float cb0 = s.bl[j], cb1 = s.bl[j + 1];
+                v2f g0, g1;
+                g0.x = i00 ? __expf(-0.5f * q0.x) : 0.0f; g0.y = i01 ? __expf(-0.5f * q0.y) : 0.0f;
+                g1.x = i10 ? __expf(-0.5f * q1.x) : 0.0f; g1.y = i11 ? __expf(-0.5f * q1.y) : 0.0f;
+                v2f al0 = b0.y * g0, al1 = b1.y * g1;
+                al0.x = fminf(al0.x, alpha_max); al0.y = fminf(al0.y, alpha_max);
+                al1.x = fminf(al1.x, alpha_max); al1.y = fminf(al1.y, alpha_max);
+                al0.x = (al0.x >= alpha_cutoff) ? al0.x : 0.0f; al0.y = (al0.y >= alpha_cutoff) ? al0.y : 0.0f;
+                al1.x = (al1.x >= alpha_cutoff) ? al1.x : 0.0f; al1.y = (al1.y >= alpha_cutoff) ? al1.y : 0.0f;
+                v2f w0 = al0 * T;
+                w0.x = (T.x > 5e-5f) ? w0.x : 0.0f; w0.y = (T.y > 5e-5f) ? w0.y : 0.0f;
+                T = T - al0 * T;
+                v2f w1 = al1 * T;
+                w1.x = (T.x > 5e-5f) ? w1.x : 0.0f; w1.y = (T.y > 5e-5f) ? w1.y : 0.0f;
+                T = T - al1 * T;
+                Cr += w0 * b0.z; Cg += w0 * b0.w; Cb += w0 * cb0;
+                Cr += w1 * b1.z; Cg += w1 * b1.w; Cb += w1 * cb1;
+            }
         }
+        alive_any = __any(T.x > 5e-5f || T.y > 5e-5f);        // once per chunk: dead pixels stay dead
     }
+    if (visited && lane == 0) visited[tile * 2 + half] = st_visited;
+    if (stats && lane == 0)
+        stats[tile * 2 + half] = WaveStats{rg.y - rg.x, st_chunks, st_visited, (uint32_t)(__builtin_amdgcn_s_memtime() - t_begin)};
     if (va) {
         const int64_t o = ((int64_t)pya * W + px) * 3;
         image[o + 0] = fminf(fmaxf(Cr.x, 0.0f), 1.0f); image[o + 1] = fminf(fmaxf(Cg.x, 0.0f), 1.0f);
@@ -407,23 +485,72 @@ __global__ __launch_bounds__(64) void raster_forward_kernel(const uint2* __restr
     }
 }
 
+// Nine per-lane partial sums -> their wave totals, total k delivered in lane k (k = 0..8) of row 0.
+// Reduce-scatter: two quad steps halve the number of live values (9 -> 5 -> 3) while summing over the quad (select +
+// DPP quad_perm add); then each lane's 3 values are summed over the 4 quads of its row (row_ror 4, 8), over the rows
+// (permlane16/32 swaps), and two DPP row shifts move values 1 and 2 next to value 0.  ~44 instructions against ~94
+// for nine independent butterfly reductions + readlane + select.
+__device__ __forceinline__ float reduce9_to_lanes(const float (&v)[9], int lane) {
+    const bool b0 = lane & 1, b1 = lane & 2;
+    float u[5], t[3];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const float lo = v[2 * i], hi = (2 * i + 1 < 9) ? v[2 * i + 1] : 0.0f;
+        const float keep = b0 ? hi : lo, send = b0 ? lo : hi;
+        u[i] = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xF, 0xF, false));
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float lo = u[2 * j], hi = (2 * j + 1 < 5) ? u[2 * j + 1] : 0.0f;
+        const float keep = b1 ? hi : lo, send = b1 ? lo : hi;
+        t[j] = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x4E, 0xF, 0xF, false));
+    }
+    // lane (b1, b0) now holds, in t[j], the quad sum of component 4 j + 2 b1 + b0
+#pragma unroll
+    for (int j = 0; j < 3; ++j) t[j] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t[j]), 0x124, 0xF, 0xF, false));
+#pragma unroll
+    for (int j = 0; j < 3; ++j) t[j] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t[j]), 0x128, 0xF, 0xF, false));
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(t[j]), __float_as_uint(t[j]), false, false);
+        t[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(t[j]), __float_as_uint(t[j]), false, false);
+        t[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    // lanes 4-7 take t[1] from lanes 0-3 (row_shr 4, bank 1), lanes 8-11 take t[2] from lanes 0-3 (row_shr 8, bank 2)
+    int out = __builtin_amdgcn_update_dpp(__float_as_int(t[0]), __float_as_int(t[1]), 0x114, 0xF, 0x2, false);
+    out = __builtin_amdgcn_update_dpp(out, __float_as_int(t[2]), 0x118, 0xF, 0x4, false);
+    return __int_as_float(out);
+}
+
 // K7: same traversal as K6 (identical T_i and alive decisions).  For pixel p and Gaussian i:
 //   d alpha_i = alive_i T_i (c_i . Gc) - (sum_{k>i} w_k (c_k . Gc)) / (1 - alpha_i),
 // the suffix sum being (total - running prefix), total = Gc . C_unclamped, Gc = dL/dO masked by the output clamp.
-// Nine per-Gaussian sums are reduced over the wave with DPP and added to grad2d[id][0..8] by lanes 0..8 (one 36-byte
-// atomic request per (half tile, Gaussian) pair that actually touched a pixel).
+// Nine per-Gaussian sums are reduced over the wave and added to grad2d[id][0..8] by lanes 0..8 (one 36-byte atomic
+// request per (half tile, Gaussian) pair that actually touched a pixel).
 __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ ids,
                                                              const f4* __restrict__ rec0, const f4* __restrict__ rec1,
-                                                             const f4* __restrict__ rec2, int tiles_x, int tiles_y, int H, int W,
-                                                             float chi, float alpha_max, float alpha_cutoff,
-                                                             const float* __restrict__ accum, const float* __restrict__ gimg,
-                                                             float* __restrict__ grad2d) {
+                                                             const f4* __restrict__ rec2, const uint32_t* __restrict__ order,
+                                                             int tiles_x, int H, int W, float chi, float alpha_max,
+                                                             float alpha_cutoff, const float* __restrict__ accum,
+                                                             const float* __restrict__ gimg, float* __restrict__ grad2d,
+                                                             WaveStats* __restrict__ stats) {
     __shared__ RasterStage s;
     const int lane = threadIdx.x;
-    int tx, ty, half;
-    if (!region_of_block(blockIdx.x, tiles_x, tiles_y, tx, ty, half)) return;
-    const uint2 rg = ranges[ty * tiles_x + tx];
+    const uint32_t tile = order[blockIdx.x >> 1];
+    const int half = blockIdx.x & 1;
+    const uint2 rg = ranges[tile];
     if (rg.x >= rg.y) return;
+    const int prio = launch_priority(blockIdx.x, gridDim.x);
+    if (prio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (prio == 1) __builtin_amdgcn_s_setprio(1);
+    const unsigned long long t_begin = stats ? __builtin_amdgcn_s_memtime() : 0ull;
+    uint32_t st_chunks = 0, st_visited = 0;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int px = tx * 16 + (lane & 15);
     const int pya = ty * 16 + half * 8 + (lane >> 4), pyb = pya + 4;
     const bool va = (px < W) && (pya < H), vb = (px < W) && (pyb < H);
@@ -453,9 +580,16 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
         suffix = v2f{sfx[0], sfx[1]};
     }
     const float x0 = (float)(tx * 16), x1 = x0 + 15.0f, y0 = (float)(ty * 16 + half * 8), y1 = y0 + 7.0f;
-    bool all_done = !__any(va || vb);
-    for (uint32_t base = rg.x; base < rg.y && !all_done; base += BATCH) {
-        const int n = stage_chunk<true>(s, lane, base, rg.y, ids, rec0, rec1, rec2, x0, x1, y0, y1);
+    bool alive_any = __any(va || vb);
+    uint32_t base = rg.x;
+    Candidate cand;
+    if (alive_any) cand = fetch_candidate(lane, base, rg.y, ids, rec0, rec1, rec2);
+    while (alive_any && base < rg.y) {
+        const int n = compact_candidates<true>(s, cand, x0, x1, y0, y1);
+        base += BATCH;
+        if (base < rg.y) cand = fetch_candidate(lane, base, rg.y, ids, rec0, rec1, rec2);   // in flight during the loop below
+        ++st_chunks;
+        st_visited += (uint32_t)n;
         for (int j = 0; j < n; ++j) {
             const f4 a = s.r0[j], b = s.r1[j];
             const float du = fpx - a.x;
@@ -489,24 +623,23 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
                 const v2f dq = (-0.5f * go) * (g * dal);
                 const v2f dvq = dv * dq;
                 const float dqs = dq.x + dq.y, dvqs = dvq.x + dvq.y;
-                const float t_A11 = du * du * dqs;
-                const float t_A12 = 2.0f * du * dvqs;
                 const v2f aA22 = dv * dvq;
-                const float t_u = -(2.0f * a.z * du * dqs + a.w * dvqs);
-                const float t_v = -(a.w * du * dqs + 2.0f * b.x * dvqs);
-                float r[9] = {t_u, t_v, t_A11, t_A12, aA22.x + aA22.y, ao.x + ao.y, ar.x + ar.y, ag.x + ag.y, ab.x + ab.y};
-                wave_total9(r);
-                if (lane < 9) {
-                    float mine = r[0];
-#pragma unroll
-                    for (int k = 1; k < 9; ++k) mine = (lane == k) ? r[k] : mine;
-                    atomicAdd(&grad2d[(int64_t)s.id[j] * 16 + lane], mine);
-                }
+                const float r[9] = {-(2.0f * a.z * du * dqs + a.w * dvqs),        // d u
+                                    -(a.w * du * dqs + 2.0f * b.x * dvqs),        // d v
+                                    du * du * dqs,                                // d A11
+                                    2.0f * du * dvqs,                             // d A12
+                                    aA22.x + aA22.y,                              // d A22
+                                    ao.x + ao.y,                                  // d opacity
+                                    ar.x + ar.y, ag.x + ag.y, ab.x + ab.y};       // d rgb
+                const float mine = reduce9_to_lanes(r, lane);
+                if (lane < 9) atomicAdd(&grad2d[(int64_t)s.id[j] * 16 + lane], mine);
             }
             T = T - al * T;
-            if (!__any(T.x > 5e-5f || T.y > 5e-5f)) { all_done = true; break; }
         }
+        alive_any = __any(T.x > 5e-5f || T.y > 5e-5f);        // once per chunk: dead pixels stay dead
     }
+    if (stats && lane == 0)
+        stats[tile * 2 + half] = WaveStats{rg.y - rg.x, st_chunks, st_visited, (uint32_t)(__builtin_amdgcn_s_memtime() - t_begin)};
 }
 
 // ---- K8 ------------------------------------------------------------------------------------------
@@ -568,6 +701,10 @@ inline unsigned blocks256(int64_t n) { return (unsigned)((n + 255) / 256); }
 extern "C" {
 
 int gsplat_abi_version(void) { return GSPLAT_ABI_VERSION; }
+
+// Diagnostics only (not declared in include/gsplat_mi355x.h): register device buffers of 2 * tiles * 16 bytes each that
+// the raster kernels fill with per-wave statistics; pass NULL to switch the statistics off again.
+void gsplat_debug_set_stats(void* fwd, void* bwd) { g_stats_fwd = (WaveStats*)fwd; g_stats_bwd = (WaveStats*)bwd; }
 
 const char* gsplat_last_error(void) { return g_err; }
 
@@ -635,7 +772,11 @@ int gsplat_bin(int64_t n, int64_t n_pairs, const gsplat_view* v, const void* pro
     ProjectState ps = carve_project((void*)project_state, n > 0 ? n : 1);
     BinState bs = carve_bin(bin_state, n_pairs, nt);
     HIP_TRY(hipMemsetAsync(bs.ranges, 0, nt * sizeof(uint2), st));
-    if (n_pairs == 0 || n == 0) return GSPLAT_OK;
+    if (n_pairs == 0 || n == 0) {
+        hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, st, (int)nt, bs.ranges, (const uint32_t*)nullptr, bs.order_fwd);
+        LAUNCH_CHECK("order_tiles_kernel");
+        return GSPLAT_OK;
+    }
     BinScratch sc = carve_bin_scratch(scratch, n_pairs);
     if (!scratch || sc.bytes > scratch_bytes) return fail(GSPLAT_ERR_WORKSPACE, "bin scratch too small");
     hipLaunchKernelGGL(emit_pairs_kernel, dim3(blocks256(n)), dim3(256), 0, st, n, ps.rec2, ps.rect, ps.tiles, ps.offsets, vk.tiles_x,
@@ -648,6 +789,8 @@ int gsplat_bin(int64_t n, int64_t n_pairs, const gsplat_view* v, const void* pro
                                       32u + tile_bits, st));
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(blocks256(n_pairs)), dim3(256), 0, st, n_pairs, sc.keys_out, bs.ranges);
     LAUNCH_CHECK("tile_ranges_kernel");
+    hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, st, (int)nt, bs.ranges, (const uint32_t*)nullptr, bs.order_fwd);
+    LAUNCH_CHECK("order_tiles_kernel");
     return GSPLAT_OK;
 }
 
@@ -661,10 +804,14 @@ int gsplat_rasterize_forward(int64_t n, int64_t n_pairs, const gsplat_view* v, c
     const int64_t nt = (int64_t)vk.tiles_x * vk.tiles_y;
     ProjectState ps = carve_project((void*)project_state, n > 0 ? n : 1);
     BinState bs = carve_bin((void*)bin_state, n_pairs, nt);
-    hipLaunchKernelGGL(raster_forward_kernel, dim3(raster_grid(vk.tiles_x, vk.tiles_y)), dim3(64), 0, st, bs.ranges, bs.sorted_ids,
-                       ps.rec0, ps.rec1, ps.rec2, vk.tiles_x, vk.tiles_y, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, image,
-                       accum);
+    hipLaunchKernelGGL(raster_forward_kernel, dim3((unsigned)(2 * nt)), dim3(64), 0, st, bs.ranges, bs.sorted_ids, ps.rec0, ps.rec1,
+                       ps.rec2, bs.order_fwd, vk.tiles_x, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, image, accum,
+                       accum ? bs.visited : (uint32_t*)nullptr, g_stats_fwd);
     LAUNCH_CHECK("raster_forward_kernel");
+    if (accum) {   // a backward pass will follow: order it by the work the forward actually did
+        hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, st, (int)nt, bs.ranges, bs.visited, bs.order_bwd);
+        LAUNCH_CHECK("order_tiles_kernel");
+    }
     return GSPLAT_OK;
 }
 
@@ -680,9 +827,9 @@ int gsplat_rasterize_backward(int64_t n, int64_t n_pairs, const gsplat_view* v, 
     BinState bs = carve_bin((void*)bin_state, n_pairs, nt);
     HIP_TRY(hipMemsetAsync(grad2d, 0, (size_t)(n > 0 ? n : 0) * 16 * sizeof(float), st));
     if (n == 0 || n_pairs == 0) return GSPLAT_OK;
-    hipLaunchKernelGGL(raster_backward_kernel, dim3(raster_grid(vk.tiles_x, vk.tiles_y)), dim3(64), 0, st, bs.ranges, bs.sorted_ids,
-                       ps.rec0, ps.rec1, ps.rec2, vk.tiles_x, vk.tiles_y, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, accum,
-                       grad_image, grad2d);
+    hipLaunchKernelGGL(raster_backward_kernel, dim3((unsigned)(2 * nt)), dim3(64), 0, st, bs.ranges, bs.sorted_ids, ps.rec0, ps.rec1,
+                       ps.rec2, bs.order_bwd, vk.tiles_x, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, accum, grad_image,
+                       grad2d, g_stats_bwd);
     LAUNCH_CHECK("raster_backward_kernel");
     return GSPLAT_OK;
 }
