@@ -54,90 +54,145 @@ GS_HD void load_cov6(const float* sigma9, float S[6]) {
     S[3] = sigma9[4]; S[4] = 0.5f * (sigma9[5] + sigma9[7]); S[5] = sigma9[8];
 }
 
-// K1 body.  Returns the VIS_* code; writes the record and tiles[i].
-template <class Coef>
-GS_HD int project_one(int64_t i, const gsplat_gaussians& g, bool fused, Coef coef, const Camera& cam, const ViewK& vk,
-                      const Records& out) {
-    const float p[3] = {g.pos[i * 3 + 0], g.pos[i * 3 + 1], g.pos[i * 3 + 2]};
+// One Gaussian's inputs as plain values (fed from global arrays by the host check, from LDS by the kernels).
+struct GaussIn {
+    float p[3];
+    float o_raw;
+    float sr[3], qr[4];     // fused inputs
+    float S9[9], col[3];    // un-fused inputs (sigma row-major, colour)
+};
+
+struct RecOut {             // what K1 stores for one Gaussian
+    f4 r0, r1, r2;
+    u2 rect;
+    uint32_t tiles;
+    int vis;
+};
+
+struct GradOut {            // what K7 stores for one Gaussian
+    float p[3], o_raw, sr[3], qr[4], S9[9], col[3];
+};
+
+// K1 core, part 1: everything except the colour.
+GS_HD Proj project_geometry(const GaussIn& in, bool fused, const Camera& cam, const ViewK& vk) {
     float S[6];
     if (fused) {
-        const float sr[3] = {g.scale_raw[i * 3 + 0], g.scale_raw[i * 3 + 1], g.scale_raw[i * 3 + 2]};
-        const float qr[4] = {g.q_raw[i * 4 + 0], g.q_raw[i * 4 + 1], g.q_raw[i * 4 + 2], g.q_raw[i * 4 + 3]};
         CovMid cm;
-        cov_from_params(sr, qr, S, cm);
+        cov_from_params(in.sr, in.qr, S, cm);
     } else {
-        load_cov6(g.sigma + i * 9, S);
+        load_cov6(in.S9, S);
     }
     Proj o; ProjMid m;
-    project_gaussian(p, S, g.opacity_raw[i], cam, vk, o, m);
-    uint32_t nt = 0;
+    project_gaussian(in.p, S, in.o_raw, cam, vk, o, m);
+    return o;
+}
+
+// K1 core, part 2: colour of a visible Gaussian (SH when fused) and the record.
+template <class Coef>
+GS_HD RecOut project_finish(const GaussIn& in, const Proj& o, bool fused, Coef coef, const Camera& cam) {
+    RecOut r;
+    r.vis = o.vis;
+    r.tiles = 0;
+    r.r0 = r.r1 = r.r2 = f4{0.f, 0.f, 0.f, 0.f};
+    r.rect = u2{0u, 0u};
     if (o.vis == VIS_OK) {
         float rgb[3];
         if (fused) {
             ShMid sm;
-            sh_basis(p, cam.eye, sm);
+            sh_basis(in.p, cam.eye, sm);
             sh_colour(sm, coef, rgb);
         } else {
-            rgb[0] = g.color[i * 3 + 0]; rgb[1] = g.color[i * 3 + 1]; rgb[2] = g.color[i * 3 + 2];
+            rgb[0] = in.col[0]; rgb[1] = in.col[1]; rgb[2] = in.col[2];
         }
-        nt = (uint32_t)((o.tx1 - o.tx0 + 1) * (o.ty1 - o.ty0 + 1));
-        out.rec0[i] = f4{o.u, o.v, o.A11, o.A12};
-        out.rec1[i] = f4{o.A22, o.opacity, o.ex, o.ey};
-        out.rec2[i] = f4{rgb[0], rgb[1], rgb[2], o.z};
-        out.rect[i] = u2{(uint32_t)o.tx0 | ((uint32_t)o.ty0 << 16), (uint32_t)o.tx1 | ((uint32_t)o.ty1 << 16)};
+        r.tiles = (uint32_t)((o.tx1 - o.tx0 + 1) * (o.ty1 - o.ty0 + 1));
+        r.r0 = f4{o.u, o.v, o.A11, o.A12};
+        r.r1 = f4{o.A22, o.opacity, o.ex, o.ey};
+        r.r2 = f4{rgb[0], rgb[1], rgb[2], o.z};
+        r.rect = u2{(uint32_t)o.tx0 | ((uint32_t)o.ty0 << 16), (uint32_t)o.tx1 | ((uint32_t)o.ty1 << 16)};
     }
-    out.tiles[i] = nt;
-    return o.vis;
+    return r;
 }
 
-// K7 body.  grad2d row = (g_u, g_v, g_A11, g_A12, g_A22, g_opacity, g_r, g_g, g_b, ...), 16 floats per Gaussian.
-// emit_rest(k, ch, val) receives dL/d(SH coefficient) for k = 0..15 (k = 0 -> f_dc).  Every output row is written.
+template <class Coef>
+GS_HD RecOut project_core(const GaussIn& in, bool fused, Coef coef, const Camera& cam, const ViewK& vk) {
+    return project_finish(in, project_geometry(in, fused, cam, vk), fused, coef, cam);
+}
+
+// K7 core.  r9 = (g_u, g_v, g_A11, g_A12, g_A22, g_opacity, g_r, g_g, g_b) of a visible Gaussian.
+// emit_sh(k, ch, val) receives dL/d(SH coefficient) for k = 0..15 (k = 0 -> f_dc); it is called for every (k, ch),
+// with zeros for a Gaussian that is not visible, so that every output row is written.
 template <class Coef, class Emit>
-GS_HD void project_backward_one(int64_t i, const gsplat_gaussians& g, bool fused, Coef coef, Emit emit_sh, const Camera& cam,
-                                const ViewK& vk, const uint32_t* tiles, const float* grad2d,
-                                const gsplat_gaussian_grads& out) {
-    float gp[3] = {0.f, 0.f, 0.f}, GS[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, go = 0.f, gsr[3] = {0, 0, 0}, gq[4] = {0, 0, 0, 0};
-    float grgb[3] = {0, 0, 0};
-    const bool vis = tiles[i] != 0;
+GS_HD GradOut project_backward_core(const GaussIn& in, bool fused, Coef coef, Emit emit_sh, const Camera& cam, const ViewK& vk,
+                                    bool vis, const float r9[9]) {
+    GradOut g;
+    for (int k = 0; k < 3; ++k) { g.p[k] = 0.f; g.sr[k] = 0.f; g.col[k] = 0.f; }
+    for (int k = 0; k < 4; ++k) g.qr[k] = 0.f;
+    for (int k = 0; k < 9; ++k) g.S9[k] = 0.f;
+    g.o_raw = 0.f;
     if (vis) {
-        const float p[3] = {g.pos[i * 3 + 0], g.pos[i * 3 + 1], g.pos[i * 3 + 2]};
         float S[6];
         CovMid cm;
-        float sr[3], qr[4];
-        if (fused) {
-            sr[0] = g.scale_raw[i * 3 + 0]; sr[1] = g.scale_raw[i * 3 + 1]; sr[2] = g.scale_raw[i * 3 + 2];
-            qr[0] = g.q_raw[i * 4 + 0]; qr[1] = g.q_raw[i * 4 + 1]; qr[2] = g.q_raw[i * 4 + 2]; qr[3] = g.q_raw[i * 4 + 3];
-            cov_from_params(sr, qr, S, cm);
-        } else {
-            load_cov6(g.sigma + i * 9, S);
-        }
+        if (fused) cov_from_params(in.sr, in.qr, S, cm);
+        else load_cov6(in.S9, S);
         Proj o; ProjMid m;
-        project_gaussian(p, S, g.opacity_raw[i], cam, vk, o, m);
-        const float* r = grad2d + i * 16;
-        project_gaussian_backward(m, o, cam, vk, r[0], r[1], r[2], r[3], r[4], r[5], gp, GS, go);
-        grgb[0] = r[6]; grgb[1] = r[7]; grgb[2] = r[8];
+        project_gaussian(in.p, S, in.o_raw, cam, vk, o, m);
+        project_gaussian_backward(m, o, cam, vk, r9[0], r9[1], r9[2], r9[3], r9[4], r9[5], g.p, g.S9, g.o_raw);
+        g.col[0] = r9[6]; g.col[1] = r9[7]; g.col[2] = r9[8];
         if (fused) {
-            cov_from_params_backward(qr, cm, GS, gsr, gq);
+            cov_from_params_backward(in.qr, cm, g.S9, g.sr, g.qr);
             ShMid sm;
-            sh_basis(p, cam.eye, sm);
+            sh_basis(in.p, cam.eye, sm);
             float rgb[3];
             sh_colour(sm, coef, rgb);
             float gps[3];
-            sh_colour_backward(sm, coef, rgb, grgb, emit_sh, gps);
-            gp[0] += gps[0]; gp[1] += gps[1]; gp[2] += gps[2];
+            sh_colour_backward(sm, coef, rgb, g.col, emit_sh, gps);
+            g.p[0] += gps[0]; g.p[1] += gps[1]; g.p[2] += gps[2];
         }
     } else if (fused) {
         for (int k = 0; k < 16; ++k)
             for (int ch = 0; ch < 3; ++ch) emit_sh(k, ch, 0.f);
     }
-    out.pos[i * 3 + 0] = gp[0]; out.pos[i * 3 + 1] = gp[1]; out.pos[i * 3 + 2] = gp[2];
-    out.opacity_raw[i] = go;
+    return g;
+}
+
+GS_HD GaussIn load_gauss_global(int64_t i, const gsplat_gaussians& g, bool fused) {
+    GaussIn in;
+    for (int k = 0; k < 3; ++k) in.p[k] = g.pos[i * 3 + k];
+    in.o_raw = g.opacity_raw[i];
     if (fused) {
-        for (int k = 0; k < 3; ++k) out.scale_raw[i * 3 + k] = gsr[k];
-        for (int k = 0; k < 4; ++k) out.q_raw[i * 4 + k] = gq[k];
+        for (int k = 0; k < 3; ++k) in.sr[k] = g.scale_raw[i * 3 + k];
+        for (int k = 0; k < 4; ++k) in.qr[k] = g.q_raw[i * 4 + k];
     } else {
-        for (int k = 0; k < 9; ++k) out.sigma[i * 9 + k] = GS[k];
-        for (int k = 0; k < 3; ++k) out.color[i * 3 + k] = grgb[k];
+        for (int k = 0; k < 9; ++k) in.S9[k] = g.sigma[i * 9 + k];
+        for (int k = 0; k < 3; ++k) in.col[k] = g.color[i * 3 + k];
+    }
+    return in;
+}
+
+// Reference-layout wrappers (host unit test; the kernels stage through LDS instead, see gsplat_kernels.hip).
+template <class Coef>
+GS_HD int project_one(int64_t i, const gsplat_gaussians& g, bool fused, Coef coef, const Camera& cam, const ViewK& vk,
+                      const Records& out) {
+    const RecOut r = project_core(load_gauss_global(i, g, fused), fused, coef, cam, vk);
+    if (r.vis == VIS_OK) { out.rec0[i] = r.r0; out.rec1[i] = r.r1; out.rec2[i] = r.r2; out.rect[i] = r.rect; }
+    out.tiles[i] = r.tiles;
+    return r.vis;
+}
+
+template <class Coef, class Emit>
+GS_HD void project_backward_one(int64_t i, const gsplat_gaussians& g, bool fused, Coef coef, Emit emit_sh, const Camera& cam,
+                                const ViewK& vk, const uint32_t* tiles, const float* grad2d,
+                                const gsplat_gaussian_grads& out) {
+    const GradOut o = project_backward_core(load_gauss_global(i, g, fused), fused, coef, emit_sh, cam, vk, tiles[i] != 0,
+                                            grad2d + i * 16);
+    out.pos[i * 3 + 0] = o.p[0]; out.pos[i * 3 + 1] = o.p[1]; out.pos[i * 3 + 2] = o.p[2];
+    out.opacity_raw[i] = o.o_raw;
+    if (fused) {
+        for (int k = 0; k < 3; ++k) out.scale_raw[i * 3 + k] = o.sr[k];
+        for (int k = 0; k < 4; ++k) out.q_raw[i * 4 + k] = o.qr[k];
+    } else {
+        for (int k = 0; k < 9; ++k) out.sigma[i * 9 + k] = o.S9[k];
+        for (int k = 0; k < 3; ++k) out.color[i * 3 + k] = o.col[k];
     }
 }
 

@@ -174,8 +174,9 @@ GS_HD void sh_colour_backward(const ShMid& m, Coef coef, const float rgb[3], con
     for (int ch = 0; ch < 3; ++ch) {
         const float dpre = g_rgb[ch] * rgb[ch] * (1.f - rgb[ch]);
         for (int k = 0; k < 16; ++k) {
+            const float cf = coef(k, ch);       // read before emit(): callers may alias the gradient onto the coefficient
             emit(k, ch, dpre * m.Y[k]);
-            dY[k] += dpre * coef(k, ch);
+            dY[k] += dpre * cf;
         }
     }
     const float x = m.d[0], y = m.d[1], z = m.d[2];

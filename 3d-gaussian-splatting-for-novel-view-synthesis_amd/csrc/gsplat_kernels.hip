@@ -56,9 +56,13 @@ struct DevCounts {           // device-side counters; copied into gsplat_counts
 };
 static_assert(sizeof(DevCounts) == sizeof(gsplat_counts), "counts layout");
 
+constexpr int COUNT_SHARDS = 256;     // per-wave counters are spread over 256 cache lines (same-address atomics serialise)
+struct alignas(64) CountShard { int32_t survivors, visible, max_tiles, pad[13]; };
+
 struct ProjectState {
     Camera* cam;
     DevCounts* counts;
+    CountShard* shards;
     f4 *rec0, *rec1, *rec2;
     u2* rect;
     uint32_t* tiles;
@@ -72,6 +76,7 @@ ProjectState carve_project(void* base, int64_t n) {
     int64_t o = 0;
     s.cam = (Camera*)(p + o); o += up(sizeof(Camera));
     s.counts = (DevCounts*)(p + o); o += up(sizeof(DevCounts));
+    s.shards = (CountShard*)(p + o); o += up(sizeof(CountShard) * COUNT_SHARDS);
     s.rec0 = (f4*)(p + o); o += up(n * 16);
     s.rec1 = (f4*)(p + o); o += up(n * 16);
     s.rec2 = (f4*)(p + o); o += up(n * 16);
@@ -159,6 +164,9 @@ int check_gaussians(const gsplat_gaussians* g, bool* fused) {
         if (f && !(g->scale_raw && g->q_raw && g->f_dc && g->f_rest)) return fail(GSPLAT_ERR_BAD_ARG, "fused inputs incomplete");
         if (u && !(g->color && g->sigma)) return fail(GSPLAT_ERR_BAD_ARG, "color / sigma is NULL");
     }
+    const void* ptrs[] = {g->pos, g->opacity_raw, g->color, g->sigma, g->scale_raw, g->q_raw, g->f_dc, g->f_rest};
+    for (const void* q : ptrs)
+        if (q && (reinterpret_cast<uintptr_t>(q) & 15u)) return fail(GSPLAT_ERR_BAD_ARG, "Gaussian arrays must be 16-byte aligned");
     *fused = f;
     return GSPLAT_OK;
 }
@@ -215,7 +223,8 @@ __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t n) {
 }
 
 // ---- K0 ------------------------------------------------------------------------------------------
-__global__ void camera_kernel(const float* __restrict__ c2w, Camera* cam, DevCounts* counts) {
+__global__ void camera_kernel(const float* __restrict__ c2w, Camera* cam, DevCounts* counts, CountShard* shards) {
+    if (threadIdx.x < COUNT_SHARDS) { shards[threadIdx.x].survivors = 0; shards[threadIdx.x].visible = 0; shards[threadIdx.x].max_tiles = 0; }
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         float m[16];
         for (int i = 0; i < 16; ++i) m[i] = c2w[i];
@@ -227,32 +236,150 @@ __global__ void camera_kernel(const float* __restrict__ c2w, Camera* cam, DevCou
 }
 
 // ---- K1 ------------------------------------------------------------------------------------------
-template <bool FUSED>
-__global__ __launch_bounds__(256) void project_kernel(gsplat_gaussians g, const Camera* __restrict__ camp, ViewK vk, Records out,
-                                                      DevCounts* counts) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const Camera cam = *camp;
-    int vis = VIS_CULLED;
-    uint32_t nt = 0;
-    if (i < g.n) {
-        ShCoefGlobal coef{FUSED ? g.f_dc + i * 3 : nullptr, FUSED ? g.f_rest + i * 45 : nullptr};
-        vis = project_one(i, g, FUSED, coef, cam, vk, out);
-        nt = out.tiles[i];
-    }
-    const unsigned long long surv = __ballot(vis != VIS_CULLED);
-    const unsigned long long seen = __ballot(vis == VIS_OK);
-    // wave max of tiles-per-Gaussian via DPP-free shuffle (rare path, tiny cost)
-    uint32_t mx = nt;
-    for (int s = 32; s > 0; s >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, s));
-    if ((threadIdx.x & 63) == 0) {
-        if (surv) atomicAdd(&counts->n_survivors, (int)__popcll(surv));
-        if (seen) atomicAdd(&counts->n_visible, (int)__popcll(seen));
-        if (mx) atomicMax(&counts->max_tiles, (int)mx);
+// One wave64 per 64 Gaussians.  The reference layout is array-of-structures (pos[N,3], f_rest[N,45] ...): a lane
+// reading its own row directly issues 45 loads that each touch 64 different cache lines.  Instead the wave copies its
+// 64 contiguous rows into LDS with fully coalesced 16-byte accesses and every lane then reads its row from LDS
+// (row strides 3, 4, 9, 45 words are conflict-free or 2-way at worst).  The SH block (f_dc + f_rest, 192 of the 236
+// input bytes) is only fetched when at least one Gaussian of the wave survived the culls.
+template <int R>
+__device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float* __restrict__ g, int64_t row0, int64_t n, int lane) {
+    const int64_t left = n - row0;
+    const int total = (int)(left < 64 ? left : 64) * R;       // floats to copy
+    const float* __restrict__ src = g + row0 * R;             // 16-B aligned: row0 % 64 == 0, base 16-B aligned (host checks)
+    constexpr int PIECES = 64 * R / 4;
+#pragma unroll
+    for (int it = 0; it < (PIECES + 63) / 64; ++it) {
+        const int piece = it * 64 + lane;
+        if (piece * 4 + 3 < total) {
+            *reinterpret_cast<f4*>(lds + piece * 4) = *reinterpret_cast<const f4*>(src + piece * 4);
+        } else if (piece * 4 < total) {
+            for (int k = piece * 4; k < total; ++k) lds[k] = src[k];
+        }
     }
 }
 
-__global__ void finish_counts_kernel(const uint32_t* __restrict__ offsets, int64_t n, DevCounts* counts) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) counts->n_pairs = n > 0 ? (int64_t)offsets[n - 1] : 0;
+template <int R>
+__device__ __forceinline__ void unstage_rows(float* __restrict__ g, const float* __restrict__ lds, int64_t row0, int64_t n, int lane) {
+    const int64_t left = n - row0;
+    const int total = (int)(left < 64 ? left : 64) * R;
+    float* __restrict__ dst = g + row0 * R;
+    constexpr int PIECES = 64 * R / 4;
+#pragma unroll
+    for (int it = 0; it < (PIECES + 63) / 64; ++it) {
+        const int piece = it * 64 + lane;
+        if (piece * 4 + 3 < total) {
+            *reinterpret_cast<f4*>(dst + piece * 4) = *reinterpret_cast<const f4*>(lds + piece * 4);
+        } else if (piece * 4 < total) {
+            for (int k = piece * 4; k < total; ++k) dst[k] = lds[k];
+        }
+    }
+}
+
+struct ProjectLds {
+    float pos[64 * 3];
+    float opa[64];
+    float a[64 * 9];        // fused: q_raw [64][4]       un-fused: sigma [64][9]
+    float b[64 * 3];        // fused: scale_raw [64][3]   un-fused: colour [64][3]
+};
+
+struct ShCoefLds {          // same access as ShCoefGlobal, on the staged copy
+    const float* dc;
+    const float* rest;
+    __device__ __forceinline__ float operator()(int k, int ch) const { return k == 0 ? dc[ch] : rest[ch * 15 + (k - 1)]; }
+};
+
+template <bool FUSED>
+__device__ __forceinline__ GaussIn gauss_from_lds(const ProjectLds& s, int lane) {
+    GaussIn in;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) in.p[k] = s.pos[lane * 3 + k];
+    in.o_raw = s.opa[lane];
+    if (FUSED) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) in.qr[k] = s.a[lane * 4 + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) in.sr[k] = s.b[lane * 3 + k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) in.S9[k] = s.a[lane * 9 + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) in.col[k] = s.b[lane * 3 + k];
+    }
+    return in;
+}
+
+template <bool FUSED>
+__device__ __forceinline__ void stage_geometry(ProjectLds& s, const gsplat_gaussians& g, int64_t row0, int lane) {
+    stage_rows<3>(s.pos, g.pos, row0, g.n, lane);
+    stage_rows<1>(s.opa, g.opacity_raw, row0, g.n, lane);
+    if (FUSED) {
+        stage_rows<4>(s.a, g.q_raw, row0, g.n, lane);
+        stage_rows<3>(s.b, g.scale_raw, row0, g.n, lane);
+    } else {
+        stage_rows<9>(s.a, g.sigma, row0, g.n, lane);
+        stage_rows<3>(s.b, g.color, row0, g.n, lane);
+    }
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const Camera* __restrict__ camp, ViewK vk, Records out,
+                                                     CountShard* shards) {
+    __shared__ ProjectLds s;
+    __shared__ float s_dc[FUSED ? 64 * 3 : 4];
+    __shared__ float s_rest[FUSED ? 64 * 45 : 4];
+    const int lane = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * 64, i = row0 + lane;
+    const Camera cam = *camp;
+    stage_geometry<FUSED>(s, g, row0, lane);
+    __syncthreads();
+    GaussIn in;
+    Proj o;
+    o.vis = VIS_CULLED;
+    if (i < g.n) {
+        in = gauss_from_lds<FUSED>(s, lane);
+        o = project_geometry(in, FUSED, cam, vk);
+    }
+    RecOut r;
+    r.vis = o.vis; r.tiles = 0;
+    if (FUSED) {
+        if (__any(o.vis == VIS_OK)) {                        // wave-uniform: skip 192 B / Gaussian when all are culled
+            stage_rows<3>(s_dc, g.f_dc, row0, g.n, lane);
+            stage_rows<45>(s_rest, g.f_rest, row0, g.n, lane);
+            __syncthreads();
+            if (o.vis == VIS_OK) r = project_finish(in, o, true, ShCoefLds{s_dc + lane * 3, s_rest + lane * 45}, cam);
+        }
+    } else if (o.vis == VIS_OK) {
+        r = project_finish(in, o, false, ShCoefLds{nullptr, nullptr}, cam);
+    }
+    if (i < g.n) {
+        if (r.vis == VIS_OK) { out.rec0[i] = r.r0; out.rec1[i] = r.r1; out.rec2[i] = r.r2; out.rect[i] = r.rect; }
+        out.tiles[i] = r.tiles;
+    }
+    const unsigned long long surv = __ballot(o.vis != VIS_CULLED);
+    const unsigned long long seen = __ballot(o.vis == VIS_OK);
+    uint32_t mx = r.tiles;
+    for (int sft = 32; sft > 0; sft >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, sft));
+    if (lane == 0) {
+        CountShard* sh = shards + (blockIdx.x % COUNT_SHARDS);
+        if (surv) atomicAdd(&sh->survivors, (int)__popcll(surv));
+        if (seen) atomicAdd(&sh->visible, (int)__popcll(seen));
+        if (mx) atomicMax(&sh->max_tiles, (int)mx);
+    }
+}
+
+__global__ __launch_bounds__(COUNT_SHARDS) void finish_counts_kernel(const uint32_t* __restrict__ offsets, int64_t n,
+                                                                     const CountShard* __restrict__ shards, DevCounts* counts) {
+    __shared__ int part[3][COUNT_SHARDS / 64];
+    int a = shards[threadIdx.x].survivors, b = shards[threadIdx.x].visible, c = shards[threadIdx.x].max_tiles;
+    for (int sft = 32; sft > 0; sft >>= 1) { a += __shfl_xor(a, sft); b += __shfl_xor(b, sft); c = max(c, __shfl_xor(c, sft)); }
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = a; part[1][threadIdx.x >> 6] = b; part[2][threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int sa = 0, sb = 0, sc = 0;
+        for (int k = 0; k < COUNT_SHARDS / 64; ++k) { sa += part[0][k]; sb += part[1][k]; sc = max(sc, part[2][k]); }
+        counts->n_survivors = sa; counts->n_visible = sb; counts->max_tiles = sc;
+        counts->n_pairs = n > 0 ? (int64_t)offsets[n - 1] : 0;
+    }
 }
 
 // ---- K3 ------------------------------------------------------------------------------------------
@@ -643,16 +770,90 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
 }
 
 // ---- K8 ------------------------------------------------------------------------------------------
+// Same per-wave LDS staging as K1 for the inputs; the gradients go the other way: every lane writes its rows into LDS
+// (f_rest gradient over the staged f_rest: each coefficient is read before its gradient is written) and the wave
+// stores the 64 rows with coalesced 16-byte accesses.  Direct per-lane stores of a [N,45] gradient wrote 3.8x the
+// algorithmic bytes (partial lines evicted before they filled).
+struct ShEmitLds {
+    float* dc;
+    float* rest;
+    __device__ __forceinline__ void operator()(int k, int ch, float v) const {
+        if (k == 0) dc[ch] = v; else rest[ch * 15 + (k - 1)] = v;
+    }
+};
+
 template <bool FUSED>
-__global__ __launch_bounds__(256) void project_backward_kernel(gsplat_gaussians g, const Camera* __restrict__ camp, ViewK vk,
-                                                               const uint32_t* __restrict__ tiles, const float* __restrict__ grad2d,
-                                                               gsplat_gaussian_grads out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= g.n) return;
+__global__ __launch_bounds__(64) void project_backward_kernel(gsplat_gaussians g, const Camera* __restrict__ camp, ViewK vk,
+                                                              const uint32_t* __restrict__ tiles, const float* __restrict__ grad2d,
+                                                              gsplat_gaussian_grads out) {
+    __shared__ ProjectLds s;
+    __shared__ float s_dc[FUSED ? 64 * 3 : 4];
+    __shared__ float s_rest[FUSED ? 64 * 45 : 4];
+    const int lane = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * 64, i = row0 + lane;
     const Camera cam = *camp;
-    ShCoefGlobal coef{FUSED ? g.f_dc + i * 3 : nullptr, FUSED ? g.f_rest + i * 45 : nullptr};
-    ShEmitGlobal emit{FUSED ? out.f_dc + i * 3 : nullptr, FUSED ? out.f_rest + i * 45 : nullptr};
-    project_backward_one(i, g, FUSED, coef, emit, cam, vk, tiles, grad2d, out);
+    const bool vis = (i < g.n) && tiles[i] != 0;
+    const bool any_vis = __any(vis);
+    float r9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (any_vis) {
+        stage_geometry<FUSED>(s, g, row0, lane);
+        if (FUSED) {
+            stage_rows<3>(s_dc, g.f_dc, row0, g.n, lane);
+            stage_rows<45>(s_rest, g.f_rest, row0, g.n, lane);
+        }
+        if (vis) {
+            const f4 g0 = *reinterpret_cast<const f4*>(grad2d + i * 16), g1 = *reinterpret_cast<const f4*>(grad2d + i * 16 + 4);
+            r9[0] = g0.x; r9[1] = g0.y; r9[2] = g0.z; r9[3] = g0.w; r9[4] = g1.x; r9[5] = g1.y; r9[6] = g1.z; r9[7] = g1.w;
+            r9[8] = grad2d[i * 16 + 8];
+        }
+    }
+    __syncthreads();
+    GradOut go;
+    if (vis) {
+        const GaussIn in = gauss_from_lds<FUSED>(s, lane);
+        go = project_backward_core(in, FUSED, ShCoefLds{s_dc + lane * 3, s_rest + lane * 45},
+                                   ShEmitLds{s_dc + lane * 3, s_rest + lane * 45}, cam, vk, true, r9);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { go.p[k] = 0.f; go.sr[k] = 0.f; go.col[k] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) go.qr[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) go.S9[k] = 0.f;
+        go.o_raw = 0.f;
+        if (FUSED) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s_dc[lane * 3 + k] = 0.f;
+            for (int k = 0; k < 45; ++k) s_rest[lane * 45 + k] = 0.f;
+        }
+    }
+    __syncthreads();      // every lane has read its inputs: the geometry buffers can take the gradients
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s.pos[lane * 3 + k] = go.p[k];
+    s.opa[lane] = go.o_raw;
+    if (FUSED) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s.a[lane * 4 + k] = go.qr[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s.b[lane * 3 + k] = go.sr[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s.a[lane * 9 + k] = go.S9[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s.b[lane * 3 + k] = go.col[k];
+    }
+    __syncthreads();
+    unstage_rows<3>(out.pos, s.pos, row0, g.n, lane);
+    unstage_rows<1>(out.opacity_raw, s.opa, row0, g.n, lane);
+    if (FUSED) {
+        unstage_rows<4>(out.q_raw, s.a, row0, g.n, lane);
+        unstage_rows<3>(out.scale_raw, s.b, row0, g.n, lane);
+        unstage_rows<3>(out.f_dc, s_dc, row0, g.n, lane);
+        unstage_rows<45>(out.f_rest, s_rest, row0, g.n, lane);
+    } else {
+        unstage_rows<9>(out.sigma, s.a, row0, g.n, lane);
+        unstage_rows<3>(out.color, s.b, row0, g.n, lane);
+    }
 }
 
 // ---- stand-alone ops -------------------------------------------------------------------------------
@@ -692,6 +893,9 @@ __global__ __launch_bounds__(256) void evaluate_sh_backward_kernel(int64_t n, co
 }
 
 inline unsigned blocks256(int64_t n) { return (unsigned)((n + 255) / 256); }
+inline unsigned blocks64(int64_t n) { return (unsigned)((n + 63) / 64); }
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace
 
@@ -741,19 +945,19 @@ int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_vie
     const int64_t n = g->n;
     ProjectState ps = carve_project(project_state, n > 0 ? n : 1);
     const ViewK vk = make_viewk(*v);
-    hipLaunchKernelGGL(camera_kernel, dim3(1), dim3(64), 0, st, c2w, ps.cam, ps.counts);
+    hipLaunchKernelGGL(camera_kernel, dim3(1), dim3(COUNT_SHARDS), 0, st, c2w, ps.cam, ps.counts, ps.shards);
     LAUNCH_CHECK("camera_kernel");
     if (n > 0) {
         Records out{ps.rec0, ps.rec1, ps.rec2, ps.rect, ps.tiles};
         if (fused)
-            hipLaunchKernelGGL(project_kernel<true>, dim3(blocks256(n)), dim3(256), 0, st, *g, ps.cam, vk, out, ps.counts);
+            hipLaunchKernelGGL(project_kernel<true>, dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, vk, out, ps.shards);
         else
-            hipLaunchKernelGGL(project_kernel<false>, dim3(blocks256(n)), dim3(256), 0, st, *g, ps.cam, vk, out, ps.counts);
+            hipLaunchKernelGGL(project_kernel<false>, dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, vk, out, ps.shards);
         LAUNCH_CHECK("project_kernel");
         size_t need = scan_temp_bytes(n);
         if (!scratch || (int64_t)need > scratch_bytes) return fail(GSPLAT_ERR_WORKSPACE, "project scratch too small");
         HIP_TRY(rocprim::inclusive_scan(scratch, need, ps.tiles, ps.offsets, (size_t)n, rocprim::plus<uint32_t>(), st));
-        hipLaunchKernelGGL(finish_counts_kernel, dim3(1), dim3(64), 0, st, ps.offsets, n, ps.counts);
+        hipLaunchKernelGGL(finish_counts_kernel, dim3(1), dim3(COUNT_SHARDS), 0, st, ps.offsets, n, ps.shards, ps.counts);
         LAUNCH_CHECK("finish_counts_kernel");
     }
     if (counts_host) HIP_TRY(hipMemcpyAsync(counts_host, ps.counts, sizeof(gsplat_counts), hipMemcpyDeviceToHost, st));
@@ -849,9 +1053,9 @@ int gsplat_project_backward(const gsplat_gaussians* g, const float* c2w, const g
     ProjectState ps = carve_project((void*)project_state, g->n);
     const ViewK vk = make_viewk(*v);
     if (fused)
-        hipLaunchKernelGGL(project_backward_kernel<true>, dim3(blocks256(g->n)), dim3(256), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out);
+        hipLaunchKernelGGL(project_backward_kernel<true>, dim3(blocks64(g->n)), dim3(64), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out);
     else
-        hipLaunchKernelGGL(project_backward_kernel<false>, dim3(blocks256(g->n)), dim3(256), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out);
+        hipLaunchKernelGGL(project_backward_kernel<false>, dim3(blocks64(g->n)), dim3(64), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out);
     LAUNCH_CHECK("project_backward_kernel");
     return GSPLAT_OK;
 }

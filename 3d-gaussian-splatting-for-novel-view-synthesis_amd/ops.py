@@ -42,7 +42,10 @@ def _f32(t, shape, name):
     t = t.detach()
     if t.dtype != torch.float32:
         t = t.float()
-    return t.contiguous()
+    t = t.contiguous()
+    if t.data_ptr() % 16:            # the kernels stage rows with 16-byte accesses (views into a larger storage may be offset)
+        t = t.clone()
+    return t
 
 
 class _Workspace:
