@@ -4,8 +4,9 @@
 //   K0 camera_kernel            c2w (device) -> Camera block                         [F5 setup]
 //   K1 project_kernel           per Gaussian: culls, EWA, eigen clamp, conic, rect   [F1-F8, F10, F13]
 //   K2 rocprim inclusive_scan   tiles-per-Gaussian -> pair offsets                   [F11]
-//   K3 emit_pairs_kernel        (tile << 32 | depth bits, id) per covered tile       [F11]
-//   K4 rocprim radix_sort_pairs stable -> (tile, depth, id) order                    [F9, F12]
+//   K3 emit_pairs_kernel        key = tile id, payload = depth bits << 32 | id        [F11]
+//   K4 rocprim radix_sort_pairs radix sort on the tile-id bits only (2 passes)       [F12]
+//   K4b tile_sort_kernel        per-tile bitonic sort of the payloads in LDS          [F9, F12]
 //   K5 tile_ranges_kernel       per-tile [start, end)                                [F12]
 //   K6 raster_forward_kernel    one wave64 per 16x8 half tile, 2 pixels per lane     [F14, F15]
 //   K7 raster_backward_kernel   same traversal, analytic gradients, wave reduction   [B1]
@@ -19,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "gs_body.h"
 
@@ -109,19 +112,22 @@ BinState carve_bin(void* base, int64_t n_pairs, int64_t n_tiles) {
     return s;
 }
 
+// Binning scratch.  Pairs are radix-sorted by tile id only (ceil(log2 tiles) key bits: 2 onesweep passes at 1080p) with a
+// 64-bit payload (depth bits << 32 | Gaussian id); the depth order inside every tile is then produced by a per-tile
+// bitonic sort in LDS (tile_sort_kernel).  Sorting 64-bit (tile, depth) keys globally took 6 passes.
 struct BinScratch {
-    uint64_t *keys_in, *keys_out;
-    uint32_t* vals_in;
-    void* sort_temp;
-    size_t sort_temp_bytes;
+    uint32_t *keys_in, *keys_out;     // [P] tile id
+    uint64_t *vals_in, *vals_out;     // [P] depth bits << 32 | id
+    void* temp;
+    size_t temp_bytes;
     int64_t bytes;
 };
 
-size_t sort_temp_bytes(int64_t n_pairs) {
-    size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                              (size_t)(n_pairs > 0 ? n_pairs : 1), 0u, 64u, (hipStream_t)0);
-    return bytes;
+size_t bin_temp_bytes(int64_t n_pairs) {
+    size_t c = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, c, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)nullptr,
+                                    (size_t)(n_pairs > 0 ? n_pairs : 1), 0u, 32u, (hipStream_t)0);
+    return c;
 }
 
 BinScratch carve_bin_scratch(void* base, int64_t n_pairs) {
@@ -129,11 +135,12 @@ BinScratch carve_bin_scratch(void* base, int64_t n_pairs) {
     char* p = (char*)base;
     int64_t o = 0;
     const int64_t np = n_pairs > 0 ? n_pairs : 1;
-    s.keys_in = (uint64_t*)(p + o); o += up(np * 8);
-    s.keys_out = (uint64_t*)(p + o); o += up(np * 8);
-    s.vals_in = (uint32_t*)(p + o); o += up(np * 4);
-    s.sort_temp_bytes = sort_temp_bytes(np);
-    s.sort_temp = (void*)(p + o); o += up((int64_t)s.sort_temp_bytes);
+    s.keys_in = (uint32_t*)(p + o); o += up(np * 4);
+    s.keys_out = (uint32_t*)(p + o); o += up(np * 4);
+    s.vals_in = (uint64_t*)(p + o); o += up(np * 8);
+    s.vals_out = (uint64_t*)(p + o); o += up(np * 8);
+    s.temp_bytes = bin_temp_bytes(np);
+    s.temp = (void*)(p + o); o += up((int64_t)s.temp_bytes);
     s.bytes = o;
     return s;
 }
@@ -385,33 +392,92 @@ __global__ __launch_bounds__(COUNT_SHARDS) void finish_counts_kernel(const uint3
 // ---- K3 ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void emit_pairs_kernel(int64_t n, const f4* __restrict__ rec2, const u2* __restrict__ rect,
                                                          const uint32_t* __restrict__ tiles, const uint32_t* __restrict__ offsets,
-                                                         int tiles_x, int64_t n_pairs, uint64_t* __restrict__ keys,
-                                                         uint32_t* __restrict__ vals) {
+                                                         int tiles_x, int64_t n_pairs, uint32_t* __restrict__ keys,
+                                                         uint64_t* __restrict__ vals) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t nt = tiles[i];
     if (nt == 0) return;
     const u2 r = rect[i];
     const int tx0 = r.x & 0xFFFF, ty0 = r.x >> 16, tx1 = r.y & 0xFFFF, ty1 = r.y >> 16;
-    const uint64_t zbits = f2u(rec2[i].w);        // z > 0: the bit pattern orders like the value
+    // z > 0: the float's bit pattern orders like its value; equal depths fall back to the Gaussian index (low word)
+    const uint64_t payload = ((uint64_t)f2u(rec2[i].w) << 32) | (uint64_t)(uint32_t)i;
     int64_t o = (int64_t)offsets[i] - nt;
     for (int ty = ty0; ty <= ty1; ++ty)
         for (int tx = tx0; tx <= tx1; ++tx) {
             if (o < n_pairs) {                     // defensive: never write past the caller's buffer
-                keys[o] = ((uint64_t)(uint32_t)(ty * tiles_x + tx) << 32) | zbits;
-                vals[o] = (uint32_t)i;
+                keys[o] = (uint32_t)(ty * tiles_x + tx);
+                vals[o] = payload;
             }
             ++o;
         }
 }
 
 // ---- K5 ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t n_pairs, const uint64_t* __restrict__ keys, uint2* ranges) {
+__global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t n_pairs, const uint32_t* __restrict__ keys, uint2* ranges) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_pairs) return;
-    const uint32_t t = (uint32_t)(keys[i] >> 32);
-    if (i == 0 || (uint32_t)(keys[i - 1] >> 32) != t) ranges[t].x = (uint32_t)i;
-    if (i == n_pairs - 1 || (uint32_t)(keys[i + 1] >> 32) != t) ranges[t].y = (uint32_t)(i + 1);
+    const uint32_t t = keys[i];
+    if (i == 0 || keys[i - 1] != t) ranges[t].x = (uint32_t)i;
+    if (i == n_pairs - 1 || keys[i + 1] != t) ranges[t].y = (uint32_t)(i + 1);
+}
+
+// ---- K4b: per-tile depth sort ----------------------------------------------------------------------
+// One workgroup per tile sorts the tile's (depth bits << 32 | id) payloads ascending with a bitonic network and writes
+// the ids.  Lists of up to TILE_SORT_LDS entries are sorted in LDS; longer ones in place in global memory by the same
+// workgroup (slow path, exact).  Keys are unique (the id is part of the key), so the result is deterministic.
+constexpr int TILE_SORT_THREADS = 256;
+constexpr int TILE_SORT_LDS = 4096;            // 32 KB of 64-bit keys
+
+// Direction-free bitonic network: every merge of size k starts with a mirror step (i <-> block_end - i), followed by
+// the half-cleaner steps j = k/4 .. 1; every compare-exchange puts the smaller key at the lower index.  With virtual
+// +inf padding above n no real element is ever exchanged with the padding, so the network also runs in place.
+template <class Get, class Swap>
+__device__ __forceinline__ void bitonic_network(uint32_t n, uint32_t m, int tid, Get get, Swap swap_if_greater) {
+    for (uint32_t k = 2; k <= m; k <<= 1) {
+        const uint32_t half = k >> 1;
+        for (uint32_t t = tid; t < (m >> 1); t += TILE_SORT_THREADS) {
+            const uint32_t r = t & (half - 1), i = ((t / half) * k) + r, l = i + (k - 1 - 2 * r);
+            if (l < n) swap_if_greater(i, l);
+        }
+        __syncthreads();
+        for (uint32_t j = half >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < (m >> 1); t += TILE_SORT_THREADS) {
+                const uint32_t i = ((t / j) * (j << 1)) + (t & (j - 1)), l = i + j;
+                if (l < n) swap_if_greater(i, l);
+            }
+            __syncthreads();
+        }
+    }
+    (void)get;
+}
+
+__global__ __launch_bounds__(TILE_SORT_THREADS) void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ vals,
+                                                                      uint32_t* __restrict__ sorted_ids) {
+    __shared__ uint64_t sk[TILE_SORT_LDS];
+    const uint2 rg = ranges[blockIdx.x];
+    const uint32_t n = rg.y - rg.x;
+    if (n == 0) return;
+    const int tid = threadIdx.x;
+    uint64_t* g = vals + rg.x;
+    uint32_t* __restrict__ out = sorted_ids + rg.x;
+    uint32_t m = 2;
+    while (m < n) m <<= 1;                     // padded size (power of two); entries >= n are virtual +inf
+    if (n <= (uint32_t)TILE_SORT_LDS) {
+        for (uint32_t i = tid; i < n; i += TILE_SORT_THREADS) sk[i] = g[i];
+        __syncthreads();
+        bitonic_network(n, m, tid, 0, [&](uint32_t i, uint32_t l) {
+            const uint64_t a = sk[i], b = sk[l];
+            if (a > b) { sk[i] = b; sk[l] = a; }
+        });
+        for (uint32_t i = tid; i < n; i += TILE_SORT_THREADS) out[i] = (uint32_t)sk[i];
+    } else {
+        bitonic_network(n, m, tid, 0, [&](uint32_t i, uint32_t l) {
+            const uint64_t a = g[i], b = g[l];
+            if (a > b) { g[i] = b; g[l] = a; }
+        });
+        for (uint32_t i = tid; i < n; i += TILE_SORT_THREADS) out[i] = (uint32_t)g[i];
+    }
 }
 
 // ---- K5b: launch order ------------------------------------------------------------------------------
@@ -986,13 +1052,17 @@ int gsplat_bin(int64_t n, int64_t n_pairs, const gsplat_view* v, const void* pro
     hipLaunchKernelGGL(emit_pairs_kernel, dim3(blocks256(n)), dim3(256), 0, st, n, ps.rec2, ps.rect, ps.tiles, ps.offsets, vk.tiles_x,
                        n_pairs, sc.keys_in, sc.vals_in);
     LAUNCH_CHECK("emit_pairs_kernel");
+    // F12 (tile part): radix sort on the tile-id bits only
     unsigned tile_bits = 1;
     while ((1LL << tile_bits) < nt) ++tile_bits;
-    size_t tb = sc.sort_temp_bytes;
-    HIP_TRY(rocprim::radix_sort_pairs(sc.sort_temp, tb, sc.keys_in, sc.keys_out, sc.vals_in, bs.sorted_ids, (size_t)n_pairs, 0u,
-                                      32u + tile_bits, st));
+    size_t tb = sc.temp_bytes;
+    HIP_TRY(rocprim::radix_sort_pairs(sc.temp, tb, sc.keys_in, sc.keys_out, sc.vals_in, sc.vals_out, (size_t)n_pairs, 0u, tile_bits,
+                                      st));
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(blocks256(n_pairs)), dim3(256), 0, st, n_pairs, sc.keys_out, bs.ranges);
     LAUNCH_CHECK("tile_ranges_kernel");
+    // F9 + F12 (depth part): per-tile sort by (depth, index)
+    hipLaunchKernelGGL(tile_sort_kernel, dim3((unsigned)nt), dim3(TILE_SORT_THREADS), 0, st, bs.ranges, sc.vals_out, bs.sorted_ids);
+    LAUNCH_CHECK("tile_sort_kernel");
     hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, st, (int)nt, bs.ranges, (const uint32_t*)nullptr, bs.order_fwd);
     LAUNCH_CHECK("order_tiles_kernel");
     return GSPLAT_OK;

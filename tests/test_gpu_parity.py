@@ -177,3 +177,34 @@ def test_seeded_scene_vs_cpu_oracle(gs, n, hw, fx, mu):
     assert np.abs(got - r64).mean() < 2e-6
     for k in util.PARAMS:
         util.check_grad(p[k].grad.cpu().numpy(), p64[k].grad.numpy(), k)
+
+
+def test_long_tile_lists_take_the_global_sort_path(gs):
+    """> 4096 Gaussians on the same tiles: the per-tile depth sort leaves LDS and sorts in global memory."""
+    n, H, W, f = 6000, 32, 48, 40.0
+    g = torch.Generator().manual_seed(11)
+    z = torch.rand(n, generator=g, dtype=torch.float64) * 4 + 2          # distinct depths
+    zs, order = torch.sort(z)
+    keep = torch.ones(n, dtype=torch.bool)
+    keep[order[1:][(zs[1:] - zs[:-1]) < 2e-5]] = False
+    uv = torch.rand(n, 2, generator=g, dtype=torch.float64) * 7.0 + 4.5            # all centres inside tile (0, 0)
+    pos = torch.stack([(uv[:, 0] - W / 2) / f * z, (uv[:, 1] - H / 2) / f * z, z], 1).float()
+    s = dict(pos=pos, scale_raw=torch.randn(n, 3, generator=g) * 0.2 - 1.6, q_raw=torch.randn(n, 4, generator=g),
+             opacity_raw=torch.randn(n, generator=g) * 0.3 - 3.6,                  # opacity ~ 0.027: thousands of layers contribute
+             f_dc=torch.randn(n, 3, generator=g), f_rest=torch.randn(n, 45, generator=g) * 0.2)
+    s = {k: v[keep].contiguous() for k, v in s.items()}
+    cam = (H, W, f, f, W / 2.0, H / 2.0)
+    c2w = torch.eye(4)
+    w = torch.rand(H, W, 3, generator=g)
+    p64 = {k: v.double().requires_grad_(True) for k, v in s.items()}
+    stages = {}
+    ref = tp.render_fused(p64["pos"], p64["f_dc"], p64["f_rest"], p64["opacity_raw"], p64["scale_raw"], p64["q_raw"],
+                          c2w.double(), *cam, stages=stages)
+    assert int((stages["tile_end"] - stages["tile_start"]).max()) > 4096
+    (ref * w.double()).sum().backward()
+    p = {k: v.to(DEV).requires_grad_(True) for k, v in s.items()}
+    img = gs.render_gaussians(p["pos"], p["f_dc"], p["f_rest"], p["opacity_raw"], p["scale_raw"], p["q_raw"], c2w.to(DEV), *cam)
+    (img * w.to(DEV)).sum().backward()
+    util.check_image(img.detach().cpu().numpy(), ref.detach().numpy(), frac=0.99)
+    for k in util.PARAMS:
+        util.check_grad(p[k].grad.cpu().numpy(), p64[k].grad.numpy(), k)
