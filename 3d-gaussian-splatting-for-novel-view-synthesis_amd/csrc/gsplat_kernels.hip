@@ -535,10 +535,13 @@ constexpr int BATCH = 64;
 struct WaveStats { uint32_t list_len, chunks, visited, cycles; };
 WaveStats* g_stats_fwd = nullptr;
 WaveStats* g_stats_bwd = nullptr;
+int g_ablate = 0;      // diagnostics: bit 0 = no atomics, bit 1 = no wave reduction (results are WRONG when set)
+
+constexpr float QK = -0.72134752044448170368f;      // -0.5 * log2(e)
 
 struct RasterStage {
-    f4 r0[BATCH + 2];      // u, v, A11, 2*A12        (+2: null records that pad an odd survivor count)
-    f4 r1[BATCH + 2];      // A22, opacity, r, g
+    f4 r0[BATCH + 2];      // u, v, k A11, 2 k A12    (+2: null records that pad an odd survivor count)
+    f4 r1[BATCH + 2];      // k A22, opacity, r, g
     float bl[BATCH + 2];   // b
     uint32_t id[BATCH + 2];
 };
@@ -577,8 +580,9 @@ __device__ __forceinline__ int compact_candidates(RasterStage& s, const Candidat
     __syncthreads();       // previous chunk's LDS reads are done (single-wave block: orders LDS traffic only)
     if (pass) {
         const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        s.r0[slot] = f4{c.q0.x, c.q0.y, c.q0.z, 2.0f * c.q0.w};
-        s.r1[slot] = f4{c.q1.x, c.q1.y, c.q2.x, c.q2.y};
+        // conic pre-scaled by k = -0.5 log2(e): the loop evaluates q' = k q and alpha = o * exp2(q') (v_exp_f32 directly)
+        s.r0[slot] = f4{c.q0.x, c.q0.y, QK * c.q0.z, (2.0f * QK) * c.q0.w};
+        s.r1[slot] = f4{QK * c.q1.x, c.q1.y, c.q2.x, c.q2.y};
         s.bl[slot] = c.q2.z;
         if (WITH_ID) s.id[slot] = c.id;
     }
@@ -622,6 +626,7 @@ __global__ __launch_bounds__(64) void raster_forward_kernel(const uint2* __restr
     v2f Cr = {0.f, 0.f}, Cg = {0.f, 0.f}, Cb = {0.f, 0.f};
     const float x0 = (float)(tx * 16), x1 = x0 + 15.0f, y0 = (float)(ty * 16 + half * 8), y1 = y0 + 7.0f;
     const uint2 rg = ranges[tile];
+    const float chik = chi * QK;
     bool alive_any = __any(va || vb);
     uint32_t base = rg.x;
     Candidate cand;
@@ -636,19 +641,20 @@ __global__ __launch_bounds__(64) void raster_forward_kernel(const uint2* __restr
             const f4 a0 = s.r0[j], b0 = s.r1[j], a1 = s.r0[j + 1], b1 = s.r1[j + 1];
             const float du0 = fpx - a0.x, du1 = fpx - a1.x;
             const v2f dv0 = fpy - a0.y, dv1 = fpy - a1.y;
-            const v2f q0 = (a0.z * du0 * du0) + dv0 * ((a0.w * du0) + b0.x * dv0);
+            const v2f q0 = (a0.z * du0 * du0) + dv0 * ((a0.w * du0) + b0.x * dv0);        // k q  (k < 0)
             const v2f q1 = (a1.z * du1 * du1) + dv1 * ((a1.w * du1) + b1.x * dv1);
-            const bool i00 = q0.x <= chi, i01 = q0.y <= chi, i10 = q1.x <= chi, i11 = q1.y <= chi;
+            const bool i00 = q0.x >= chik, i01 = q0.y >= chik, i10 = q1.x >= chik, i11 = q1.y >= chik;   // q <= chi
             if (__any(i00 || i01 || i10 || i11)) {
                 const float cb0 = s.bl[j], cb1 = s.bl[j + 1];
                 v2f g0, g1;
-                g0.x = i00 ? __expf(-0.5f * q0.x) : 0.0f; g0.y = i01 ? __expf(-0.5f * q0.y) : 0.0f;
-                g1.x = i10 ? __expf(-0.5f * q1.x) : 0.0f; g1.y = i11 ? __expf(-0.5f * q1.y) : 0.0f;
+                g0.x = __builtin_amdgcn_exp2f(q0.x); g0.y = __builtin_amdgcn_exp2f(q0.y);
+                g1.x = __builtin_amdgcn_exp2f(q1.x); g1.y = __builtin_amdgcn_exp2f(q1.y);
                 v2f al0 = b0.y * g0, al1 = b1.y * g1;
                 al0.x = fminf(al0.x, alpha_max); al0.y = fminf(al0.y, alpha_max);
                 al1.x = fminf(al1.x, alpha_max); al1.y = fminf(al1.y, alpha_max);
-                al0.x = (al0.x >= alpha_cutoff) ? al0.x : 0.0f; al0.y = (al0.y >= alpha_cutoff) ? al0.y : 0.0f;
-                al1.x = (al1.x >= alpha_cutoff) ? al1.x : 0.0f; al1.y = (al1.y >= alpha_cutoff) ? al1.y : 0.0f;
+                // alpha = 0 outside the chi-square clip and below the cutoff (one select for both)
+                al0.x = (i00 && al0.x >= alpha_cutoff) ? al0.x : 0.0f; al0.y = (i01 && al0.y >= alpha_cutoff) ? al0.y : 0.0f;
+                al1.x = (i10 && al1.x >= alpha_cutoff) ? al1.x : 0.0f; al1.y = (i11 && al1.y >= alpha_cutoff) ? al1.y : 0.0f;
                 v2f w0 = al0 * T;
                 w0.x = (T.x > 5e-5f) ? w0.x : 0.0f; w0.y = (T.y > 5e-5f) ? w0.y : 0.0f;
                 T = T - al0 * T;
@@ -730,7 +736,7 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
                                                              int tiles_x, int H, int W, float chi, float alpha_max,
                                                              float alpha_cutoff, const float* __restrict__ accum,
                                                              const float* __restrict__ gimg, float* __restrict__ grad2d,
-                                                             WaveStats* __restrict__ stats) {
+                                                             WaveStats* __restrict__ stats, int ablate) {
     __shared__ RasterStage s;
     const int lane = threadIdx.x;
     const uint32_t tile = order[blockIdx.x >> 1];
@@ -773,6 +779,7 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
         suffix = v2f{sfx[0], sfx[1]};
     }
     const float x0 = (float)(tx * 16), x1 = x0 + 15.0f, y0 = (float)(ty * 16 + half * 8), y1 = y0 + 7.0f;
+    const float chik = chi * QK;
     bool alive_any = __any(va || vb);
     uint32_t base = rg.x;
     Candidate cand;
@@ -788,17 +795,17 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
             const float du = fpx - a.x;
             const v2f dv = fpy - a.y;
             const float c0 = a.z * du * du, c1 = a.w * du;
-            const v2f q = c0 + dv * (c1 + b.x * dv);
-            const bool i0 = q.x <= chi, i1 = q.y <= chi;
+            const v2f q = c0 + dv * (c1 + b.x * dv);                                   // k q  (k < 0)
+            const bool i0 = q.x >= chik, i1 = q.y >= chik;                              // q <= chi
             if (!__any(i0 || i1)) continue;
             const float cbl = s.bl[j], go = b.y;
             v2f g;
-            g.x = i0 ? __expf(-0.5f * q.x) : 0.0f;
-            g.y = i1 ? __expf(-0.5f * q.y) : 0.0f;
+            g.x = __builtin_amdgcn_exp2f(q.x);
+            g.y = __builtin_amdgcn_exp2f(q.y);
             const v2f og = go * g;
             v2f al;
             al.x = fminf(og.x, alpha_max); al.y = fminf(og.y, alpha_max);
-            al.x = (al.x >= alpha_cutoff) ? al.x : 0.0f; al.y = (al.y >= alpha_cutoff) ? al.y : 0.0f;
+            al.x = (i0 && al.x >= alpha_cutoff) ? al.x : 0.0f; al.y = (i1 && al.y >= alpha_cutoff) ? al.y : 0.0f;
             const bool act0 = (T.x > 5e-5f) && (al.x > 0.0f), act1 = (T.y > 5e-5f) && (al.y > 0.0f);
             if (__any(act0 || act1)) {
                 v2f w = al * T;
@@ -813,19 +820,29 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
                 dal.x = (act0 && og.x <= alpha_max) ? dal.x : 0.0f;
                 dal.y = (act1 && og.y <= alpha_max) ? dal.y : 0.0f;
                 const v2f ao = dal * g;
-                const v2f dq = (-0.5f * go) * (g * dal);
+                const v2f dq = (-0.5f * go) * (g * dal);                       // dL/dq (q un-scaled)
                 const v2f dvq = dv * dq;
                 const float dqs = dq.x + dq.y, dvqs = dvq.x + dvq.y;
                 const v2f aA22 = dv * dvq;
-                const float r[9] = {-(2.0f * a.z * du * dqs + a.w * dvqs),        // d u
-                                    -(a.w * du * dqs + 2.0f * b.x * dvqs),        // d v
+                // the staged conic is k * (A11, 2 A12, A22): undo the scale with 1/k for the two position gradients
+                const float r[9] = {-(2.0f * a.z * du * dqs + a.w * dvqs) * (1.0f / QK),        // d u
+                                    -(a.w * du * dqs + 2.0f * b.x * dvqs) * (1.0f / QK),        // d v
                                     du * du * dqs,                                // d A11
                                     2.0f * du * dvqs,                             // d A12
                                     aA22.x + aA22.y,                              // d A22
                                     ao.x + ao.y,                                  // d opacity
                                     ar.x + ar.y, ag.x + ag.y, ab.x + ab.y};       // d rgb
-                const float mine = reduce9_to_lanes(r, lane);
-                if (lane < 9) atomicAdd(&grad2d[(int64_t)s.id[j] * 16 + lane], mine);
+                float mine;
+                if (ablate & 2) {
+                    mine = r[0] + r[1] + r[2] + r[3] + r[4] + r[5] + r[6] + r[7] + r[8];
+                } else {
+                    mine = reduce9_to_lanes(r, lane);
+                }
+                if (ablate & 1) {
+                    asm volatile("" ::"v"(mine));
+                } else if (lane < 9) {
+                    atomicAdd(&grad2d[(int64_t)s.id[j] * 16 + lane], mine);
+                }
             }
             T = T - al * T;
         }
@@ -975,6 +992,7 @@ int gsplat_abi_version(void) { return GSPLAT_ABI_VERSION; }
 // Diagnostics only (not declared in include/gsplat_mi355x.h): register device buffers of 2 * tiles * 16 bytes each that
 // the raster kernels fill with per-wave statistics; pass NULL to switch the statistics off again.
 void gsplat_debug_set_stats(void* fwd, void* bwd) { g_stats_fwd = (WaveStats*)fwd; g_stats_bwd = (WaveStats*)bwd; }
+void gsplat_debug_set_ablation(int bits) { g_ablate = bits; }
 
 const char* gsplat_last_error(void) { return g_err; }
 
@@ -1103,7 +1121,7 @@ int gsplat_rasterize_backward(int64_t n, int64_t n_pairs, const gsplat_view* v, 
     if (n == 0 || n_pairs == 0) return GSPLAT_OK;
     hipLaunchKernelGGL(raster_backward_kernel, dim3((unsigned)(2 * nt)), dim3(64), 0, st, bs.ranges, bs.sorted_ids, ps.rec0, ps.rec1,
                        ps.rec2, bs.order_bwd, vk.tiles_x, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, accum, grad_image,
-                       grad2d, g_stats_bwd);
+                       grad2d, g_stats_bwd, g_ablate);
     LAUNCH_CHECK("raster_backward_kernel");
     return GSPLAT_OK;
 }
