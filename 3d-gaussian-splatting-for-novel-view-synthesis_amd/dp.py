@@ -27,15 +27,43 @@ def _big_and_small(grads):
     return order[0], order[1:]
 
 
+def _common_base(grads):
+    """If all gradient tensors are disjoint contiguous views into ONE storage that they (nearly) cover -- what the render
+    backward produces (ops._flat_like) -- return a flat tensor spanning them, else None.  Detected through the storage,
+    because autograd detaches the tensors it puts into .grad."""
+    g0 = grads[0]
+    try:
+        sp = g0.untyped_storage().data_ptr()
+        if any((not g.is_contiguous()) or g.dtype != g0.dtype or g.device != g0.device or
+               g.untyped_storage().data_ptr() != sp for g in grads):
+            return None
+        spans = sorted((g.storage_offset(), g.storage_offset() + g.numel()) for g in grads)
+    except (RuntimeError, AttributeError):
+        return None
+    if any(a_end > b_start for (_, a_end), (b_start, _) in zip(spans, spans[1:])):
+        return None                                           # overlapping views
+    lo, hi = spans[0][0], spans[-1][1]
+    if hi - lo > sum(g.numel() for g in grads) + 64 * len(grads):
+        return None                                           # too much foreign data in between
+    return torch.empty(0, dtype=g0.dtype, device=g0.device).set_(g0.untyped_storage(), lo, (hi - lo,))
+
+
 def allreduce_gradients(grads, world_views, group=None):
     """Sum gradient tensors over ranks and scale by 1 / world_views (== loss / batch_size in the reference).
 
-    grads: list of tensors (same shapes on every rank), modified in place.  Returns the list.
+    grads: list of tensors (same shapes on every rank), modified in place.  Returns the list.  When the tensors are the
+    views of one flat buffer produced by the render backward, a single in-place all-reduce of that buffer is issued.
     """
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         if world_views != 1:
             for g in grads:
                 g.mul_(1.0 / world_views)
+        return grads
+    base = _common_base(grads)
+    if base is not None:
+        dist.all_reduce(base, op=dist.ReduceOp.SUM, group=group)
+        if world_views != 1:
+            base.mul_(1.0 / world_views)
         return grads
     big, small = _big_and_small(grads)
     works = [dist.all_reduce(grads[big], op=dist.ReduceOp.SUM, group=group, async_op=True)]

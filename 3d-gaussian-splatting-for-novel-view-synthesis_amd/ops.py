@@ -185,6 +185,18 @@ def _forward_impl(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad):
     return image, fr, counts
 
 
+def _flat_like(ins):
+    """One flat fp32 buffer holding a gradient for every input (each view 256-byte aligned inside it).  The data-parallel
+    helper recognises the shared base and all-reduces the six gradients with ONE in-place collective, no flatten copy."""
+    offs, total = {}, 0
+    for k, v in ins.items():
+        offs[k] = total
+        total += (v.numel() + 63) // 64 * 64
+    any_in = next(iter(ins.values()))
+    flat = torch.empty(total, dtype=torch.float32, device=any_in.device)
+    return {k: flat[offs[k]:offs[k] + v.numel()].view(v.shape) for k, v in ins.items()}
+
+
 def _backward_impl(fr, grad_image):
     """Returns a dict name -> fp32 gradient tensor for every input of the forward call."""
     lib = _abi.lib()
@@ -199,7 +211,7 @@ def _backward_impl(fr, grad_image):
         with _stage("raster_backward"):
             _abi.check(lib.gsplat_rasterize_backward(fr.n, fr.n_pairs, C.byref(fr.view), _p(fr.proj_state), _p(fr.bin_state),
                                                      _p(fr.accum), _p(gi), _p(grad2d), st), "gsplat_rasterize_backward")
-        out = {k: torch.empty_like(v) for k, v in ins.items()}
+        out = _flat_like(ins)
         g = _make_gaussians(fr.n, **ins)
         gg = _abi.GaussianGrads(_p(out["pos"]), _p(out["opacity_raw"]), _p(out.get("color")), _p(out.get("sigma")),
                                 _p(out.get("scale_raw")), _p(out.get("q_raw")), _p(out.get("f_dc")), _p(out.get("f_rest")))

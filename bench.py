@@ -170,6 +170,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=256)
     ap.add_argument("--cpu-budget", type=int, default=150, help="seconds allowed for the CPU baseline leg")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -188,13 +190,16 @@ def main():
                   "sample": f"failed: {type(e).__name__}: {e}"}
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if args.single_device else local_rank)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     gs = importlib.import_module(PKG)
     ops = importlib.import_module(PKG + ".ops")
@@ -209,6 +214,8 @@ def main():
     gimg = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(1)).to(dev)
     cam_args = (H, W, cam["fx"], cam["fy"], cam["cx"], cam["cy"])
 
+    info = {"allreduce": None}
+
     def step():
         if need_grad:
             for p in params.values():
@@ -216,7 +223,9 @@ def main():
             img = gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args)
             img.backward(gimg)
             if world > 1:
-                dp.allreduce_gradients([params[k].grad for k in NAMES], world_views=world)
+                grads = [params[k].grad for k in NAMES]
+                info["allreduce"] = "one flat buffer, single collective" if dp._common_base(grads) is not None else "2 buckets"
+                dp.allreduce_gradients(grads, world_views=world)
         else:
             with torch.no_grad():
                 img = gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args)
@@ -268,7 +277,7 @@ def main():
                                    f"{'forward+backward' if need_grad else 'forward only'}, one camera view per GPU per step"
                                    + (", RCCL all-reduce of 6 gradient tensors" if world > 1 and need_grad else ""),
                        "N": N, "V": V, "P": P, "tiles": math.ceil(H / 16) * math.ceil(W / 16),
-                       "parallelism": f"dp{world} by camera view"},
+                       "parallelism": f"dp{world} by camera view", "allreduce": info["allreduce"]},
             "fps": world * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(KERNEL_OF_STAGE[dom]), "kernel": KERNEL_OF_STAGE[dom],

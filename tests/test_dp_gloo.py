@@ -31,6 +31,16 @@ def _worker(rank, world, port, q):
     dp = importlib.import_module(PKG + ".dp")
     grads = _grads(rank)
     dp.allreduce_gradients(grads, world_views=world)
+    # same gradients as views of one flat buffer (what the render backward produces): single-collective path
+    ops = importlib.import_module(PKG + ".ops")
+    views = ops._flat_like({k: g for k, g in zip(SHAPES, _grads(rank))})
+    for v, g in zip(views.values(), _grads(rank)):
+        v.copy_(g)
+    vl = list(views.values())
+    assert dp._common_base(vl) is not None
+    dp.allreduce_gradients(vl, world_views=world)
+    for v, g in zip(vl, grads):
+        assert torch.allclose(v, g, atol=1e-6)
     # a DP step through the helper with a toy differentiable "renderer" (the HIP op needs a GPU)
     params = {k: torch.full(s, 0.5, requires_grad=True) for k, s in SHAPES.items()}
     views = dp.shard_views(4, rank, world)
