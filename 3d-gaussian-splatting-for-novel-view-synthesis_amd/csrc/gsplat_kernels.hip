@@ -426,57 +426,64 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t n_pairs, const
 // One workgroup per tile sorts the tile's (depth bits << 32 | id) payloads ascending with a bitonic network and writes
 // the ids.  Lists of up to TILE_SORT_LDS entries are sorted in LDS; longer ones in place in global memory by the same
 // workgroup (slow path, exact).  Keys are unique (the id is part of the key), so the result is deterministic.
-constexpr int TILE_SORT_THREADS = 256;
-constexpr int TILE_SORT_LDS = 4096;            // 32 KB of 64-bit keys
+// Two size classes share the code: lists of up to 512 entries (almost all tiles) use 128 threads and 4 KB of LDS, so
+// 16 workgroups fit a CU; longer lists use 256 threads and 32 KB.  Each launch covers all tiles and a workgroup
+// returns at once when its tile belongs to the other class.
+constexpr int TILE_SORT_LDS = 4096;            // largest list sorted in LDS (32 KB of 64-bit keys)
+constexpr int TILE_SORT_SMALL = 512;
 
 // Direction-free bitonic network: every merge of size k starts with a mirror step (i <-> block_end - i), followed by
 // the half-cleaner steps j = k/4 .. 1; every compare-exchange puts the smaller key at the lower index.  With virtual
 // +inf padding above n no real element is ever exchanged with the padding, so the network also runs in place.
-template <class Get, class Swap>
-__device__ __forceinline__ void bitonic_network(uint32_t n, uint32_t m, int tid, Get get, Swap swap_if_greater) {
-    for (uint32_t k = 2; k <= m; k <<= 1) {
-        const uint32_t half = k >> 1;
-        for (uint32_t t = tid; t < (m >> 1); t += TILE_SORT_THREADS) {
-            const uint32_t r = t & (half - 1), i = ((t / half) * k) + r, l = i + (k - 1 - 2 * r);
+template <int THREADS, class Swap>
+__device__ __forceinline__ void bitonic_network(uint32_t n, uint32_t m, int tid, Swap swap_if_greater) {
+    uint32_t lk = 1;                                              // log2(k)
+    for (uint32_t k = 2; k <= m; k <<= 1, ++lk) {
+        const uint32_t half = k >> 1, lh = lk - 1;
+        for (uint32_t t = tid; t < (m >> 1); t += THREADS) {
+            const uint32_t r = t & (half - 1), i = ((t >> lh) << lk) + r, l = i + (k - 1 - 2 * r);
             if (l < n) swap_if_greater(i, l);
         }
         __syncthreads();
+        uint32_t lj = lh;                                         // log2(j) + 1
         for (uint32_t j = half >> 1; j > 0; j >>= 1) {
-            for (uint32_t t = tid; t < (m >> 1); t += TILE_SORT_THREADS) {
-                const uint32_t i = ((t / j) * (j << 1)) + (t & (j - 1)), l = i + j;
+            --lj;
+            for (uint32_t t = tid; t < (m >> 1); t += THREADS) {
+                const uint32_t i = ((t >> lj) << (lj + 1)) + (t & (j - 1)), l = i + j;
                 if (l < n) swap_if_greater(i, l);
             }
             __syncthreads();
         }
     }
-    (void)get;
 }
 
-__global__ __launch_bounds__(TILE_SORT_THREADS) void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ vals,
-                                                                      uint32_t* __restrict__ sorted_ids) {
-    __shared__ uint64_t sk[TILE_SORT_LDS];
+template <int THREADS, int CAP, bool LARGE>
+__global__ __launch_bounds__(THREADS) void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ vals,
+                                                            uint32_t* __restrict__ sorted_ids) {
+    __shared__ uint64_t sk[CAP];
     const uint2 rg = ranges[blockIdx.x];
     const uint32_t n = rg.y - rg.x;
     if (n == 0) return;
+    if (LARGE ? (n <= (uint32_t)TILE_SORT_SMALL) : (n > (uint32_t)TILE_SORT_SMALL)) return;     // the other launch's tile
     const int tid = threadIdx.x;
     uint64_t* g = vals + rg.x;
     uint32_t* __restrict__ out = sorted_ids + rg.x;
     uint32_t m = 2;
     while (m < n) m <<= 1;                     // padded size (power of two); entries >= n are virtual +inf
-    if (n <= (uint32_t)TILE_SORT_LDS) {
-        for (uint32_t i = tid; i < n; i += TILE_SORT_THREADS) sk[i] = g[i];
+    if (n <= (uint32_t)CAP) {
+        for (uint32_t i = tid; i < n; i += THREADS) sk[i] = g[i];
         __syncthreads();
-        bitonic_network(n, m, tid, 0, [&](uint32_t i, uint32_t l) {
+        bitonic_network<THREADS>(n, m, tid, [&](uint32_t i, uint32_t l) {
             const uint64_t a = sk[i], b = sk[l];
             if (a > b) { sk[i] = b; sk[l] = a; }
         });
-        for (uint32_t i = tid; i < n; i += TILE_SORT_THREADS) out[i] = (uint32_t)sk[i];
+        for (uint32_t i = tid; i < n; i += THREADS) out[i] = (uint32_t)sk[i];
     } else {
-        bitonic_network(n, m, tid, 0, [&](uint32_t i, uint32_t l) {
+        bitonic_network<THREADS>(n, m, tid, [&](uint32_t i, uint32_t l) {
             const uint64_t a = g[i], b = g[l];
             if (a > b) { g[i] = b; g[l] = a; }
         });
-        for (uint32_t i = tid; i < n; i += TILE_SORT_THREADS) out[i] = (uint32_t)g[i];
+        for (uint32_t i = tid; i < n; i += THREADS) out[i] = (uint32_t)g[i];
     }
 }
 
@@ -1079,8 +1086,12 @@ int gsplat_bin(int64_t n, int64_t n_pairs, const gsplat_view* v, const void* pro
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(blocks256(n_pairs)), dim3(256), 0, st, n_pairs, sc.keys_out, bs.ranges);
     LAUNCH_CHECK("tile_ranges_kernel");
     // F9 + F12 (depth part): per-tile sort by (depth, index)
-    hipLaunchKernelGGL(tile_sort_kernel, dim3((unsigned)nt), dim3(TILE_SORT_THREADS), 0, st, bs.ranges, sc.vals_out, bs.sorted_ids);
-    LAUNCH_CHECK("tile_sort_kernel");
+    hipLaunchKernelGGL((tile_sort_kernel<128, TILE_SORT_SMALL, false>), dim3((unsigned)nt), dim3(128), 0, st, bs.ranges, sc.vals_out,
+                       bs.sorted_ids);
+    LAUNCH_CHECK("tile_sort_kernel<small>");
+    hipLaunchKernelGGL((tile_sort_kernel<256, TILE_SORT_LDS, true>), dim3((unsigned)nt), dim3(256), 0, st, bs.ranges, sc.vals_out,
+                       bs.sorted_ids);
+    LAUNCH_CHECK("tile_sort_kernel<large>");
     hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, st, (int)nt, bs.ranges, (const uint32_t*)nullptr, bs.order_fwd);
     LAUNCH_CHECK("order_tiles_kernel");
     return GSPLAT_OK;
