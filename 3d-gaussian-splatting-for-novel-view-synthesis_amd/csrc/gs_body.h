@@ -13,16 +13,19 @@ GS_HD float u2f(uint32_t u) { union { float f; uint32_t u; } c; c.u = u; return 
 
 struct u2 { uint32_t x, y; };
 
-// Projected record, 48 B per Gaussian in three 16-B streams (SoA of float4) + the tile rectangle:
-//   rec0 = (u, v, A11, A12)   rec1 = (A22, opacity, ex, ey)   rec2 = (r, g, b, depth z)
-//   rect = (tx0 | ty0 << 16, tx1 | ty1 << 16)   inclusive tile rectangle
+// Projected record: ONE 64-byte line per Gaussian (the rasterizer gathers records by id; three separate 16-byte
+// streams cost three cache lines per gather), plus small per-Gaussian streams for the binning kernels:
+//   rec[i] = { (u, v, A11, A12), (A22, opacity, ex, ey), (r, g, b, depth z), (unused) }
+//   rect[i] = (tx0 | ty0 << 16, tx1 | ty1 << 16)   inclusive tile rectangle
+//   depth[i] = z                                   tiles[i] = tiles touched (0 = not visible)
 // (ex, ey) are the half-extents of {q <= chi_square_clip}: the rasterizer culls with them at staging time.
+struct alignas(64) Rec64 { f4 r0, r1, r2, pad; };
+
 struct Records {
-    f4* rec0;
-    f4* rec1;
-    f4* rec2;
+    Rec64* rec;
     u2* rect;
-    uint32_t* tiles;      // tiles touched per Gaussian (0 = not visible)
+    float* depth;
+    uint32_t* tiles;
 };
 
 GS_HD ViewK make_viewk(const gsplat_view& v) {
@@ -174,7 +177,10 @@ template <class Coef>
 GS_HD int project_one(int64_t i, const gsplat_gaussians& g, bool fused, Coef coef, const Camera& cam, const ViewK& vk,
                       const Records& out) {
     const RecOut r = project_core(load_gauss_global(i, g, fused), fused, coef, cam, vk);
-    if (r.vis == VIS_OK) { out.rec0[i] = r.r0; out.rec1[i] = r.r1; out.rec2[i] = r.r2; out.rect[i] = r.rect; }
+    if (r.vis == VIS_OK) {
+        out.rec[i].r0 = r.r0; out.rec[i].r1 = r.r1; out.rec[i].r2 = r.r2;
+        out.rect[i] = r.rect; out.depth[i] = r.r2.w;
+    }
     out.tiles[i] = r.tiles;
     return r.vis;
 }

@@ -66,8 +66,9 @@ struct ProjectState {
     Camera* cam;
     DevCounts* counts;
     CountShard* shards;
-    f4 *rec0, *rec1, *rec2;
+    Rec64* rec;
     u2* rect;
+    float* depth;
     uint32_t* tiles;
     uint32_t* offsets;       // inclusive prefix sum of tiles
     int64_t bytes;
@@ -80,10 +81,9 @@ ProjectState carve_project(void* base, int64_t n) {
     s.cam = (Camera*)(p + o); o += up(sizeof(Camera));
     s.counts = (DevCounts*)(p + o); o += up(sizeof(DevCounts));
     s.shards = (CountShard*)(p + o); o += up(sizeof(CountShard) * COUNT_SHARDS);
-    s.rec0 = (f4*)(p + o); o += up(n * 16);
-    s.rec1 = (f4*)(p + o); o += up(n * 16);
-    s.rec2 = (f4*)(p + o); o += up(n * 16);
+    s.rec = (Rec64*)(p + o); o += up(n * 64);
     s.rect = (u2*)(p + o); o += up(n * 8);
+    s.depth = (float*)(p + o); o += up(n * 4);
     s.tiles = (uint32_t*)(p + o); o += up(n * 4);
     s.offsets = (uint32_t*)(p + o); o += up(n * 4);
     s.bytes = o;
@@ -359,7 +359,13 @@ __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const C
         r = project_finish(in, o, false, ShCoefLds{nullptr, nullptr}, cam);
     }
     if (i < g.n) {
-        if (r.vis == VIS_OK) { out.rec0[i] = r.r0; out.rec1[i] = r.r1; out.rec2[i] = r.r2; out.rect[i] = r.rect; }
+        if (r.vis == VIS_OK) {
+            Rec64 line;
+            line.r0 = r.r0; line.r1 = r.r1; line.r2 = r.r2; line.pad = f4{0.f, 0.f, 0.f, 0.f};
+            out.rec[i] = line;                   // 64 contiguous bytes per lane, 4 KB per wave
+            out.rect[i] = r.rect;
+            out.depth[i] = r.r2.w;
+        }
         out.tiles[i] = r.tiles;
     }
     const unsigned long long surv = __ballot(o.vis != VIS_CULLED);
@@ -390,7 +396,7 @@ __global__ __launch_bounds__(COUNT_SHARDS) void finish_counts_kernel(const uint3
 }
 
 // ---- K3 ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void emit_pairs_kernel(int64_t n, const f4* __restrict__ rec2, const u2* __restrict__ rect,
+__global__ __launch_bounds__(256) void emit_pairs_kernel(int64_t n, const float* __restrict__ depth, const u2* __restrict__ rect,
                                                          const uint32_t* __restrict__ tiles, const uint32_t* __restrict__ offsets,
                                                          int tiles_x, int64_t n_pairs, uint32_t* __restrict__ keys,
                                                          uint64_t* __restrict__ vals) {
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(256) void emit_pairs_kernel(int64_t n, const f4* __
     const u2 r = rect[i];
     const int tx0 = r.x & 0xFFFF, ty0 = r.x >> 16, tx1 = r.y & 0xFFFF, ty1 = r.y >> 16;
     // z > 0: the float's bit pattern orders like its value; equal depths fall back to the Gaussian index (low word)
-    const uint64_t payload = ((uint64_t)f2u(rec2[i].w) << 32) | (uint64_t)(uint32_t)i;
+    const uint64_t payload = ((uint64_t)f2u(depth[i]) << 32) | (uint64_t)(uint32_t)i;
     int64_t o = (int64_t)offsets[i] - nt;
     for (int ty = ty0; ty <= ty1; ++ty)
         for (int tx = tx0; tx <= tx1; ++tx) {
@@ -560,8 +566,7 @@ struct Candidate {         // one list entry held by one lane between fetch and 
 };
 
 __device__ __forceinline__ Candidate fetch_candidate(int lane, uint32_t base, uint32_t end, const uint32_t* __restrict__ ids,
-                                                     const f4* __restrict__ rec0, const f4* __restrict__ rec1,
-                                                     const f4* __restrict__ rec2) {
+                                                     const Rec64* __restrict__ rec) {
     Candidate c;
     const uint32_t idx = base + lane;
     c.valid = idx < end;
@@ -569,9 +574,10 @@ __device__ __forceinline__ Candidate fetch_candidate(int lane, uint32_t base, ui
     c.q0 = c.q1 = c.q2 = f4{0.f, 0.f, 0.f, 0.f};
     if (c.valid) {
         c.id = ids[idx];
-        c.q0 = rec0[c.id];
-        c.q1 = rec1[c.id];
-        c.q2 = rec2[c.id];
+        const Rec64* __restrict__ r = rec + c.id;        // one 64-byte line
+        c.q0 = r->r0;
+        c.q1 = r->r1;
+        c.q2 = r->r2;
     }
     return c;
 }
@@ -607,8 +613,7 @@ __device__ __forceinline__ int launch_priority(uint32_t b, uint32_t grid) {
 }
 
 __global__ __launch_bounds__(64) void raster_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ ids,
-                                                            const f4* __restrict__ rec0, const f4* __restrict__ rec1,
-                                                            const f4* __restrict__ rec2, const uint32_t* __restrict__ order,
+                                                            const Rec64* __restrict__ rec, const uint32_t* __restrict__ order,
                                                             int tiles_x, int H, int W, float chi, float alpha_max,
                                                             float alpha_cutoff, float* __restrict__ image,
                                                             float* __restrict__ accum, uint32_t* __restrict__ visited,
@@ -637,11 +642,11 @@ __global__ __launch_bounds__(64) void raster_forward_kernel(const uint2* __restr
     bool alive_any = __any(va || vb);
     uint32_t base = rg.x;
     Candidate cand;
-    if (alive_any && base < rg.y) cand = fetch_candidate(lane, base, rg.y, ids, rec0, rec1, rec2);
+    if (alive_any && base < rg.y) cand = fetch_candidate(lane, base, rg.y, ids, rec);
     while (alive_any && base < rg.y) {
         const int n = compact_candidates<false>(s, cand, x0, x1, y0, y1);
         base += BATCH;
-        if (base < rg.y) cand = fetch_candidate(lane, base, rg.y, ids, rec0, rec1, rec2);   // in flight during the loop below
+        if (base < rg.y) cand = fetch_candidate(lane, base, rg.y, ids, rec);   // in flight during the loop below
         ++st_chunks;
         st_visited += (uint32_t)n;
         for (int j = 0; j < n; j += 2) {
@@ -738,8 +743,7 @@ __device__ __forceinline__ float reduce9_to_lanes(const float (&v)[9], int lane)
 // Nine per-Gaussian sums are reduced over the wave and added to grad2d[id][0..8] by lanes 0..8 (one 36-byte atomic
 // request per (half tile, Gaussian) pair that actually touched a pixel).
 __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ ids,
-                                                             const f4* __restrict__ rec0, const f4* __restrict__ rec1,
-                                                             const f4* __restrict__ rec2, const uint32_t* __restrict__ order,
+                                                             const Rec64* __restrict__ rec, const uint32_t* __restrict__ order,
                                                              int tiles_x, int H, int W, float chi, float alpha_max,
                                                              float alpha_cutoff, const float* __restrict__ accum,
                                                              const float* __restrict__ gimg, float* __restrict__ grad2d,
@@ -790,11 +794,11 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
     bool alive_any = __any(va || vb);
     uint32_t base = rg.x;
     Candidate cand;
-    if (alive_any) cand = fetch_candidate(lane, base, rg.y, ids, rec0, rec1, rec2);
+    if (alive_any) cand = fetch_candidate(lane, base, rg.y, ids, rec);
     while (alive_any && base < rg.y) {
         const int n = compact_candidates<true>(s, cand, x0, x1, y0, y1);
         base += BATCH;
-        if (base < rg.y) cand = fetch_candidate(lane, base, rg.y, ids, rec0, rec1, rec2);   // in flight during the loop below
+        if (base < rg.y) cand = fetch_candidate(lane, base, rg.y, ids, rec);   // in flight during the loop below
         ++st_chunks;
         st_visited += (uint32_t)n;
         for (int j = 0; j < n; ++j) {
@@ -1039,7 +1043,7 @@ int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_vie
     hipLaunchKernelGGL(camera_kernel, dim3(1), dim3(COUNT_SHARDS), 0, st, c2w, ps.cam, ps.counts, ps.shards);
     LAUNCH_CHECK("camera_kernel");
     if (n > 0) {
-        Records out{ps.rec0, ps.rec1, ps.rec2, ps.rect, ps.tiles};
+        Records out{ps.rec, ps.rect, ps.depth, ps.tiles};
         if (fused)
             hipLaunchKernelGGL(project_kernel<true>, dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, vk, out, ps.shards);
         else
@@ -1074,7 +1078,7 @@ int gsplat_bin(int64_t n, int64_t n_pairs, const gsplat_view* v, const void* pro
     }
     BinScratch sc = carve_bin_scratch(scratch, n_pairs);
     if (!scratch || sc.bytes > scratch_bytes) return fail(GSPLAT_ERR_WORKSPACE, "bin scratch too small");
-    hipLaunchKernelGGL(emit_pairs_kernel, dim3(blocks256(n)), dim3(256), 0, st, n, ps.rec2, ps.rect, ps.tiles, ps.offsets, vk.tiles_x,
+    hipLaunchKernelGGL(emit_pairs_kernel, dim3(blocks256(n)), dim3(256), 0, st, n, ps.depth, ps.rect, ps.tiles, ps.offsets, vk.tiles_x,
                        n_pairs, sc.keys_in, sc.vals_in);
     LAUNCH_CHECK("emit_pairs_kernel");
     // F12 (tile part): radix sort on the tile-id bits only
@@ -1107,8 +1111,8 @@ int gsplat_rasterize_forward(int64_t n, int64_t n_pairs, const gsplat_view* v, c
     const int64_t nt = (int64_t)vk.tiles_x * vk.tiles_y;
     ProjectState ps = carve_project((void*)project_state, n > 0 ? n : 1);
     BinState bs = carve_bin((void*)bin_state, n_pairs, nt);
-    hipLaunchKernelGGL(raster_forward_kernel, dim3((unsigned)(2 * nt)), dim3(64), 0, st, bs.ranges, bs.sorted_ids, ps.rec0, ps.rec1,
-                       ps.rec2, bs.order_fwd, vk.tiles_x, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, image, accum,
+    hipLaunchKernelGGL(raster_forward_kernel, dim3((unsigned)(2 * nt)), dim3(64), 0, st, bs.ranges, bs.sorted_ids, ps.rec,
+                       bs.order_fwd, vk.tiles_x, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, image, accum,
                        accum ? bs.visited : (uint32_t*)nullptr, g_stats_fwd);
     LAUNCH_CHECK("raster_forward_kernel");
     if (accum) {   // a backward pass will follow: order it by the work the forward actually did
@@ -1130,8 +1134,8 @@ int gsplat_rasterize_backward(int64_t n, int64_t n_pairs, const gsplat_view* v, 
     BinState bs = carve_bin((void*)bin_state, n_pairs, nt);
     HIP_TRY(hipMemsetAsync(grad2d, 0, (size_t)(n > 0 ? n : 0) * 16 * sizeof(float), st));
     if (n == 0 || n_pairs == 0) return GSPLAT_OK;
-    hipLaunchKernelGGL(raster_backward_kernel, dim3((unsigned)(2 * nt)), dim3(64), 0, st, bs.ranges, bs.sorted_ids, ps.rec0, ps.rec1,
-                       ps.rec2, bs.order_bwd, vk.tiles_x, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, accum, grad_image,
+    hipLaunchKernelGGL(raster_backward_kernel, dim3((unsigned)(2 * nt)), dim3(64), 0, st, bs.ranges, bs.sorted_ids, ps.rec,
+                       bs.order_bwd, vk.tiles_x, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, accum, grad_image,
                        grad2d, g_stats_bwd, g_ablate);
     LAUNCH_CHECK("raster_backward_kernel");
     return GSPLAT_OK;

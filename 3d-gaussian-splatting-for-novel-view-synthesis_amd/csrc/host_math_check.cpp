@@ -9,12 +9,12 @@ using namespace gsm;
 
 extern "C" {
 
-void hm_project(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, float* rec0, float* rec1, float* rec2,
-                uint32_t* rect, uint32_t* tiles, int32_t* vis) {
+void hm_project(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, float* rec64, uint32_t* rect, float* depth,
+                uint32_t* tiles, int32_t* vis) {
     Camera cam; build_camera(c2w, cam);
     const ViewK vk = make_viewk(*v);
     const bool fused = g->scale_raw != nullptr;
-    Records out{(f4*)rec0, (f4*)rec1, (f4*)rec2, (u2*)rect, tiles};
+    Records out{(Rec64*)rec64, (u2*)rect, depth, tiles};
     for (int64_t i = 0; i < g->n; ++i) {
         ShCoefGlobal coef{fused ? g->f_dc + i * 3 : nullptr, fused ? g->f_rest + i * 45 : nullptr};
         vis[i] = project_one(i, *g, fused, coef, cam, vk, out);

@@ -44,14 +44,16 @@ def _gaussians(arrs, fused=True, color=None, sigma=None):
 def _project(hm, d, arrs, fused=True, color=None, sigma=None):
     n = len(arrs["pos"])
     view = abi.make_view(*util.cam_args(d), **d["kwargs"])
-    rec = [np.zeros((n, 4), np.float32) for _ in range(3)]
-    rec.append(np.zeros((n, 2), np.uint32))     # rec[3] = tile rectangle
+    rec64 = np.zeros((n, 16), np.float32)        # one 64-byte record per Gaussian
+    rect = np.zeros((n, 2), np.uint32)
+    depth = np.zeros(n, np.float32)
     tiles = np.zeros(n, np.uint32)
     vis = np.zeros(n, np.int32)
     g = _gaussians(arrs, fused, color, sigma)
     c2w = np.ascontiguousarray(d["c2w"], np.float32)
-    hm.hm_project(C.byref(g), _ptr(c2w), C.byref(view), _ptr(rec[0]), _ptr(rec[1]), _ptr(rec[2]), _ptr(rec[3]), _ptr(tiles),
-                  _ptr(vis))
+    hm.hm_project(C.byref(g), _ptr(c2w), C.byref(view), _ptr(rec64), _ptr(rect), _ptr(depth), _ptr(tiles), _ptr(vis))
+    assert np.array_equal(depth[vis == 0], rec64[vis == 0, 11])
+    rec = [rec64[:, 0:4], rec64[:, 4:8], rec64[:, 8:12], rect]
     return rec, tiles, vis, view, g, c2w
 
 
