@@ -13,6 +13,8 @@ plus the fused entry `render_gaussians` and the data-parallel helpers in `.dp`.
 from .ops import (HARMONICS, build_sigma_from_params, evaluate_sh, inv2x2, project_points, quat_to_rotmat, render,
                   render_gaussians, render_stats, scale_intrinsics)
 
+from . import losses  # noqa: E402,F401  (L1 + SSIM loss)
+from .losses import compute_loss  # noqa: E402,F401
 from . import dp  # noqa: E402,F401  (data-parallel-by-view helpers)
 
 __all__ = [

@@ -63,6 +63,8 @@ SIGNATURES = {
     "gsplat_build_sigma_backward": (_INT, [_I64, _VP, _VP, _VP, _VP, _VP, _VP]),
     "gsplat_evaluate_sh": (_INT, [_I64, _VP, _VP, _VP, _VP, _VP, _VP]),
     "gsplat_evaluate_sh_backward": (_INT, [_I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "gsplat_loss_scratch_bytes": (_I64, []),
+    "gsplat_loss": (_INT, [_VP, _VP, _I64, C.c_int32, C.c_int32, C.c_float, C.c_float, _VP, _VP, _VP, _VP]),
 }
 
 _lib = None

@@ -27,9 +27,11 @@
 
 using namespace gsm;
 
+thread_local char gsplat_err_buf[512] = "";      // shared with gsplat_loss.hip; read through gsplat_last_error()
+
 namespace {
 
-thread_local char g_err[512] = "";
+char (&g_err)[512] = gsplat_err_buf;
 
 int fail(int code, const char* fmt, const char* a = "", const char* b = "") {
     snprintf(g_err, sizeof(g_err), fmt, a, b);

@@ -1,0 +1,203 @@
+// gsplat_loss.hip -- fused L1 + SSIM training loss (value AND gradient w.r.t. the prediction in one pass).
+//
+// SURVEY.md §8(f) "next" row 1: reference gaussian_splatting/losses.py:27-185 (l1_loss, ssim_loss, _ssim_single_channel,
+// _create_gaussian_window, compute_loss).  The reference runs 15 conv2d calls on permuted copies per view and autograd
+// replays them; here one kernel reads pred/target once and writes the gradient once.
+//
+//   L = l1w * mean|x - y| + sw * (1 - mean SSIM),      SSIM per channel with an 11 x 11 Gaussian window (sigma 1.5),
+//   zero padding, C1 = 0.01^2, C2 = 0.03^2; the 2-D window is the outer product of a normalised 1-D Gaussian, so every
+//   convolution is done separably.
+//
+// Gradient: with mu1 = w*x, mu2 = w*y, E11 = w*x^2, E22 = w*y^2, E12 = w*xy (w* = windowed sum) and
+//   S = A1 A2 / (B1 B2),  A1 = 2 mu1 mu2 + C1, A2 = 2 (E12 - mu1 mu2) + C2, B1 = mu1^2 + mu2^2 + C1,
+//   B2 = E11 - mu1^2 + E22 - mu2^2 + C2:
+//   dS/dmu1 = 2 mu2 (A2 - A1) / (B1 B2) - 2 mu1 S / B1 + 2 mu1 S / B2,   dS/dE11 = -S / B2,   dS/dE12 = 2 A1 / (B1 B2),
+//   d(sum S)/dx(q) = (w * dS/dmu1)(q) + 2 x(q) (w * dS/dE11)(q) + y(q) (w * dS/dE12)(q)     (w is symmetric).
+//
+// One workgroup per 32 x 16 output tile and image; the three channels are processed one after the other through the
+// same LDS buffers: inputs with a 10-pixel halo, five horizontally filtered planes, the three partial-derivative maps
+// with a 5-pixel halo, their horizontally filtered planes.  Sums go to 64 shards (same-address atomics serialise).
+#include <cstdio>
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/gsplat_mi355x.h"
+
+namespace {
+
+constexpr int TW = 32, TH = 16, R = 5, TAPS = 11;
+constexpr int W0 = TW + 4 * R, H0 = TH + 4 * R;      // input region   52 x 36
+constexpr int W1 = TW + 2 * R, H1 = TH + 2 * R;      // map region     42 x 26
+constexpr int THREADS = 256, SHARDS = 64;
+
+struct LossLds {
+    float x[H0][W0], y[H0][W0];
+    float h[5][H0][W1];          // horizontally filtered x, y, xx, yy, xy; later: q[3][H1][TW]
+    float p[3][H1][W1];          // dS/dmu1, dS/dE11, dS/dE12 (zero outside the image)
+};
+
+__device__ __forceinline__ void gauss_taps(float g[TAPS]) {
+    // losses.py:131-155: exp(-(i - 5)^2 / (2 * 1.5^2)), normalised
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < TAPS; ++i) { const float d = (float)(i - R); g[i] = expf(-(d * d) / 4.5f); s += g[i]; }
+    const float inv = 1.0f / s;
+#pragma unroll
+    for (int i = 0; i < TAPS; ++i) g[i] *= inv;
+}
+
+__global__ __launch_bounds__(THREADS) void loss_kernel(const float* __restrict__ pred, const float* __restrict__ target, int H, int W,
+                                                       float l1w, float sw, float inv_n, float* __restrict__ sums,
+                                                       float* __restrict__ grad) {
+    __shared__ LossLds s;
+    __shared__ float red[2][THREADS / 64];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int64_t img = (int64_t)blockIdx.z * H * W * 3;
+    float g[TAPS];
+    gauss_taps(g);
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    float l1_acc = 0.f, ssim_acc = 0.f;
+    for (int ch = 0; ch < 3; ++ch) {
+        __syncthreads();
+        // 1. inputs with a 2R halo, zero outside the image (= the reference's zero padding)
+        for (int i = tid; i < H0 * W0; i += THREADS) {
+            const int r = i / W0, c = i - r * W0;
+            const int gy = y0 - 2 * R + r, gx = x0 - 2 * R + c;
+            float a = 0.f, b = 0.f;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const int64_t o = img + ((int64_t)gy * W + gx) * 3 + ch;
+                a = pred[o]; b = target[o];
+            }
+            s.x[r][c] = a; s.y[r][c] = b;
+        }
+        __syncthreads();
+        // 2. horizontal pass of the five products
+        for (int i = tid; i < H0 * W1; i += THREADS) {
+            const int r = i / W1, c = i - r * W1;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const float a = s.x[r][c + t], b = s.y[r][c + t], w = g[t];
+                a0 += w * a; a1 += w * b; a2 += w * a * a; a3 += w * b * b; a4 += w * a * b;
+            }
+            s.h[0][r][c] = a0; s.h[1][r][c] = a1; s.h[2][r][c] = a2; s.h[3][r][c] = a3; s.h[4][r][c] = a4;
+        }
+        __syncthreads();
+        // 3. vertical pass -> SSIM map and its partial derivatives on the tile + R halo
+        for (int i = tid; i < H1 * W1; i += THREADS) {
+            const int r = i / W1, c = i - r * W1;
+            const int gy = y0 - R + r, gx = x0 - R + c;
+            float dmu = 0.f, d11 = 0.f, d12 = 0.f;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    const float w = g[t];
+                    mu1 += w * s.h[0][r + t][c]; mu2 += w * s.h[1][r + t][c]; e11 += w * s.h[2][r + t][c];
+                    e22 += w * s.h[3][r + t][c]; e12 += w * s.h[4][r + t][c];
+                }
+                const float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * (e12 - mu1 * mu2) + C2;
+                const float B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = (e11 - mu1 * mu1) + (e22 - mu2 * mu2) + C2;
+                const float ib = 1.0f / (B1 * B2);
+                const float S = A1 * A2 * ib;
+                dmu = 2.f * mu2 * (A2 - A1) * ib - 2.f * mu1 * S / B1 + 2.f * mu1 * S / B2;
+                d11 = -S / B2;
+                d12 = 2.f * A1 * ib;
+                if (r >= R && r < R + TH && c >= R && c < R + TW) ssim_acc += S;
+            }
+            s.p[0][r][c] = dmu; s.p[1][r][c] = d11; s.p[2][r][c] = d12;
+        }
+        __syncthreads();
+        // 4. horizontal pass of the three derivative maps (into the h buffer, which is free now)
+        float(*q)[H1][TW] = reinterpret_cast<float(*)[H1][TW]>(&s.h[0][0][0]);
+        for (int i = tid; i < H1 * TW; i += THREADS) {
+            const int r = i / TW, c = i - r * TW;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const float w = g[t];
+                a0 += w * s.p[0][r][c + t]; a1 += w * s.p[1][r][c + t]; a2 += w * s.p[2][r][c + t];
+            }
+            q[0][r][c] = a0; q[1][r][c] = a1; q[2][r][c] = a2;
+        }
+        __syncthreads();
+        // 5. vertical pass + L1 term -> gradient of this channel
+        for (int i = tid; i < TH * TW; i += THREADS) {
+            const int r = i / TW, c = i - r * TW;
+            const int gy = y0 + r, gx = x0 + c;
+            if (gy < H && gx < W) {
+                float cm = 0.f, c11 = 0.f, c12 = 0.f;
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    const float w = g[t];
+                    cm += w * q[0][r + t][c]; c11 += w * q[1][r + t][c]; c12 += w * q[2][r + t][c];
+                }
+                const float a = s.x[r + 2 * R][c + 2 * R], b = s.y[r + 2 * R][c + 2 * R];
+                const float d = a - b;
+                l1_acc += fabsf(d);
+                if (grad) {
+                    const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+                    grad[img + ((int64_t)gy * W + gx) * 3 + ch] = inv_n * (l1w * sgn - sw * (cm + 2.f * a * c11 + b * c12));
+                }
+            }
+        }
+    }
+    // block reduction of the two sums, one atomic pair per block into a shard
+    for (int sft = 32; sft > 0; sft >>= 1) { l1_acc += __shfl_xor(l1_acc, sft); ssim_acc += __shfl_xor(ssim_acc, sft); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = l1_acc; red[1][tid >> 6] = ssim_acc; }
+    __syncthreads();
+    if (tid == 0) {
+        float a = 0.f, b = 0.f;
+        for (int k = 0; k < THREADS / 64; ++k) { a += red[0][k]; b += red[1][k]; }
+        const int shard = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * gridDim.x * gridDim.y) % SHARDS;
+        atomicAdd(&sums[shard * 2 + 0], a);
+        atomicAdd(&sums[shard * 2 + 1], b);
+    }
+}
+
+__global__ void loss_zero_kernel(float* sums) {
+    if (threadIdx.x < SHARDS * 2) sums[threadIdx.x] = 0.f;
+}
+
+__global__ void loss_finish_kernel(const float* __restrict__ sums, double inv_n, float l1w, float sw, float* __restrict__ values) {
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < SHARDS; ++k) { a += sums[2 * k]; b += sums[2 * k + 1]; }
+        const double l1 = a * inv_n, sl = 1.0 - b * inv_n;
+        values[0] = (float)l1; values[1] = (float)sl; values[2] = (float)(l1w * l1 + sw * sl);
+    }
+}
+
+}  // namespace
+
+extern thread_local char gsplat_err_buf[512];
+#define g_loss_err gsplat_err_buf
+
+extern "C" {
+
+int64_t gsplat_loss_scratch_bytes(void) { return SHARDS * 2 * sizeof(float); }
+
+int gsplat_loss(const float* pred, const float* target, int64_t batch, int32_t H, int32_t W, float lambda_l1, float lambda_ssim,
+                float* values, float* grad_pred, void* scratch, void* stream_) {
+    if (!pred || !target || !values || !scratch || batch <= 0 || H <= 0 || W <= 0 || batch > 65535) {
+        snprintf(g_loss_err, sizeof(g_loss_err), "gsplat_loss: bad argument");
+        return GSPLAT_ERR_BAD_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream_;
+    float* sums = (float*)scratch;
+    const double n = (double)batch * H * W * 3;
+    hipLaunchKernelGGL(loss_zero_kernel, dim3(1), dim3(SHARDS * 2), 0, st, sums);
+    const dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, (unsigned)batch);
+    hipLaunchKernelGGL(loss_kernel, grid, dim3(THREADS), 0, st, pred, target, (int)H, (int)W, lambda_l1, lambda_ssim, (float)(1.0 / n), sums,
+                       grad_pred);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, st, sums, 1.0 / n, lambda_l1, lambda_ssim, values);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_loss_err, sizeof(g_loss_err), "gsplat_loss launch: %s", hipGetErrorString(e));
+        return GSPLAT_ERR_HIP;
+    }
+    return GSPLAT_OK;
+}
+
+}  // extern "C"

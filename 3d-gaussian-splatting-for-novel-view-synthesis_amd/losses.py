@@ -1,0 +1,65 @@
+"""Training loss of the reference (gaussian_splatting/losses.py) on the MI355X: L1 + SSIM, value and gradient from one
+fused HIP kernel (csrc/gsplat_loss.hip) -- SURVEY.md §8(f), "next" row 1.
+
+Same names, arguments and return values as the reference:
+    l1_loss(pred, target)                                              losses.py:27
+    ssim_loss(pred, target, window_size=11, size_average=True)         losses.py:44
+    compute_loss(pred, target, lambda_l1=0.8, lambda_ssim=0.2)         losses.py:158  -> (total, {'l1', 'ssim', 'total'})
+pred / target: [H, W, 3] or [B, H, W, 3].  Differentiable w.r.t. `pred` (the reference never needs d/d target).
+"""
+import ctypes as C
+
+import torch
+
+from . import _abi
+from .ops import _f32, _p, _stage, _stream_ptr
+
+
+class _LossFn(torch.autograd.Function):
+    """values = (l1, 1 - ssim, l1w * l1 + sw * (1 - ssim)); the gradient of values[2] w.r.t. pred comes out of the same
+    kernel launch and is only scaled in backward()."""
+
+    @staticmethod
+    def forward(ctx, pred, target, l1w, sw):
+        lib = _abi.lib()
+        shape = tuple(pred.shape)
+        if len(shape) not in (3, 4) or shape[-1] != 3 or tuple(target.shape) != shape:
+            raise ValueError(f"pred/target must both be [H, W, 3] or [B, H, W, 3], got {shape} and {tuple(target.shape)}")
+        b = shape[0] if len(shape) == 4 else 1
+        h, w = shape[-3], shape[-2]
+        x, y = _f32(pred, shape, "pred"), _f32(target, shape, "target")
+        dev = x.device
+        need = ctx.needs_input_grad[0]
+        with torch.cuda.device(dev):
+            values = torch.empty(3, dtype=torch.float32, device=dev)
+            grad = torch.empty_like(x) if need else None
+            scratch = torch.empty(lib.gsplat_loss_scratch_bytes(), dtype=torch.uint8, device=dev)
+            with _stage("loss"):
+                _abi.check(lib.gsplat_loss(_p(x), _p(y), b, h, w, float(l1w), float(sw), _p(values), _p(grad), _p(scratch),
+                                           _stream_ptr(dev)), "gsplat_loss")
+        ctx.grad = grad
+        ctx.dtype = pred.dtype
+        return values
+
+    @staticmethod
+    def backward(ctx, g):
+        out = ctx.grad * g[2]
+        return (out if ctx.dtype == torch.float32 else out.to(ctx.dtype)), None, None, None
+
+
+def compute_loss(pred, target, lambda_l1=0.8, lambda_ssim=0.2):
+    """lambda_l1 * L1 + lambda_ssim * (1 - SSIM); returns (total_loss, dict of floats) like the reference."""
+    v = _LossFn.apply(pred, target, lambda_l1, lambda_ssim)
+    total = v[2]
+    l1, ssim, tot = v.detach().tolist()              # ONE host read instead of the reference's three .item() calls
+    return (total if pred.dtype == torch.float32 else total.to(pred.dtype)), {'l1': l1, 'ssim': ssim, 'total': tot}
+
+
+def l1_loss(pred, target):
+    return _LossFn.apply(pred, target, 1.0, 0.0)[2].to(pred.dtype)
+
+
+def ssim_loss(pred, target, window_size=11, size_average=True):
+    if window_size != 11 or not size_average:
+        raise NotImplementedError("the fused kernel implements the reference defaults: window_size=11, size_average=True")
+    return _LossFn.apply(pred, target, 0.0, 1.0)[2].to(pred.dtype)

@@ -152,6 +152,15 @@ int gsplat_evaluate_sh_backward(int64_t n, const float* f_dc, const float* f_res
                                 const float* c2w, const float* grad_color, float* grad_f_dc, float* grad_f_rest,
                                 float* grad_points, void* stream);
 
+/* ---- next row of the path: the training loss ------------------------------------
+ * compute_loss() of the reference (gaussian_splatting/losses.py:158-185; l1_loss :27, ssim_loss :44,
+ * 11 x 11 Gaussian window, sigma 1.5, zero padding): lambda_l1 * mean|pred - target| + lambda_ssim * (1 - SSIM).
+ * pred/target/grad_pred are [batch, H, W, 3] fp32 device arrays.  values[3] (device) receives (l1, 1 - ssim, total);
+ * grad_pred (nullable) receives d total / d pred.  scratch: gsplat_loss_scratch_bytes() device bytes.            */
+int64_t gsplat_loss_scratch_bytes(void);
+int gsplat_loss(const float* pred, const float* target, int64_t batch, int32_t H, int32_t W, float lambda_l1,
+                float lambda_ssim, float* values, float* grad_pred, void* scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

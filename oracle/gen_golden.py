@@ -227,6 +227,30 @@ def gen_pieces():
          proj_uv=uv.numpy(), proj_xyz=torch.stack([x, y, z], 1).numpy())
 
 
+def gen_loss():
+    """Next-row fixture: compute_loss (gaussian_splatting/losses.py:158-185) forward + d/dpred, float64."""
+    print("loss")
+    import importlib
+    losses = importlib.import_module("gaussian_splatting.losses")
+    rng = np.random.default_rng(411)
+    out = {}
+    for tag, shape in (("a", (45, 70, 3)), ("b", (2, 40, 52, 3)), ("c", (9, 7, 3))):
+        tgt = rng.uniform(0, 1, shape).astype(np.float32)
+        pred = np.clip(tgt + rng.normal(0, 0.15, shape), 0, 1).astype(np.float32)
+        pred[..., :3, :, :][..., :2, :] = tgt[..., :3, :, :][..., :2, :]          # some exactly equal pixels: sign(0) = 0
+        p = _t(pred, torch.float64, True)
+        total, parts = losses.compute_loss(p, _t(tgt, torch.float64), 0.8, 0.2)
+        total.backward()
+        out.update({f"pred_{tag}": pred, f"target_{tag}": tgt, f"grad_{tag}": p.grad.numpy(),
+                    f"vals_{tag}": np.array([parts["l1"], parts["ssim"], parts["total"]])})
+        p2 = _t(pred, torch.float64, True)
+        t2, _ = losses.compute_loss(p2, _t(tgt, torch.float64), 0.3, 1.7)
+        t2.backward()
+        out.update({f"grad2_{tag}": p2.grad.numpy(), f"total2_{tag}": np.array(float(t2))})
+        print(f"  {tag} {shape}: l1 {parts['l1']:.5f} ssim-loss {parts['ssim']:.5f} total {parts['total']:.5f}")
+    save("loss", **out)
+
+
 def gen_config1():
     """G12: config 1 at full size (10k Gaussians, 256x256, f_rest = 0): image + gradient digests."""
     name = "g13_config1_full"
@@ -260,3 +284,5 @@ if __name__ == "__main__":
         gen_pieces()
     if not want or "g13_config1_full" in want:
         gen_config1()
+    if not want or "loss" in want:
+        gen_loss()

@@ -140,3 +140,19 @@ def test_config1_full_digest():
         g = p[k].grad.numpy()
         assert abs(np.linalg.norm(g) - float(d["gnorm_" + k])) <= 1e-8 * float(d["gnorm_" + k])
         assert np.allclose(g[:1024], d["grad_" + k + "_head"], rtol=1e-4, atol=1e-6 * np.abs(g).max())
+
+
+def test_loss_vs_reference():
+    d = dict(np.load(util.GOLDEN + "/loss.npz"))
+    for tag in "abc":
+        p = torch.tensor(d["pred_" + tag], dtype=F64, requires_grad=True)
+        t = torch.tensor(d["target_" + tag], dtype=F64)
+        total, l1, sl = tp.compute_loss(p, t, 0.8, 0.2)
+        total.backward()
+        assert np.allclose([float(l1), float(sl), float(total)], d["vals_" + tag], rtol=1e-12, atol=1e-14)
+        assert np.abs(p.grad.numpy() - d["grad_" + tag]).max() < 1e-14
+        p2 = torch.tensor(d["pred_" + tag], dtype=F64, requires_grad=True)
+        t2, _, _ = tp.compute_loss(p2, t, 0.3, 1.7)
+        t2.backward()
+        assert abs(float(t2) - float(d["total2_" + tag])) < 1e-13
+        assert np.abs(p2.grad.numpy() - d["grad2_" + tag]).max() < 1e-13
