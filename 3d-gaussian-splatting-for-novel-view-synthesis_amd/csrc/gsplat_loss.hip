@@ -30,11 +30,15 @@ constexpr int W0 = TW + 4 * R, H0 = TH + 4 * R;      // input region   52 x 36
 constexpr int W1 = TW + 2 * R, H1 = TH + 2 * R;      // map region     42 x 26
 constexpr int THREADS = 256, SHARDS = 64;
 
+constexpr int W0P = W0 + 4;      // row pitch of the input planes (register-blocked passes may read a few columns past W0)
+
 struct LossLds {
-    float x[H0][W0], y[H0][W0];
-    float h[5][H0][W1];          // horizontally filtered x, y, xx, yy, xy; later: q[3][H1][TW]
-    float p[3][H1][W1];          // dS/dmu1, dS/dE11, dS/dE12 (zero outside the image)
+    float x[H0][W0P], y[H0][W0P];
+    float h[5][H0 + 2][W1];      // horizontally filtered x, y, xx, yy, xy (+2 slack rows); later: q[3][H1][TW]
+    float p[3][H1][W1 + 2];      // dS/dmu1, dS/dE11, dS/dE12 (zero outside the image; +2 slack columns)
 };
+// Every pass is register-blocked: a thread produces G consecutive outputs along the filter direction from G + 10 inputs
+// held in registers, so an output costs (G + 10) / G LDS reads per plane instead of 11.
 
 __device__ __forceinline__ void gauss_taps(float g[TAPS]) {
     // losses.py:131-155: exp(-(i - 5)^2 / (2 * 1.5^2)), normalised
@@ -72,73 +76,100 @@ __global__ __launch_bounds__(THREADS) void loss_kernel(const float* __restrict__
             s.x[r][c] = a; s.y[r][c] = b;
         }
         __syncthreads();
-        // 2. horizontal pass of the five products
-        for (int i = tid; i < H0 * W1; i += THREADS) {
-            const int r = i / W1, c = i - r * W1;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+        // 2. horizontal pass of the five products: 3 outputs per thread (W1 = 14 * 3)
+        for (int i = tid; i < H0 * (W1 / 3); i += THREADS) {
+            const int r = i / (W1 / 3), c = (i - r * (W1 / 3)) * 3;
+            float a[13], b[13];
 #pragma unroll
-            for (int t = 0; t < TAPS; ++t) {
-                const float a = s.x[r][c + t], b = s.y[r][c + t], w = g[t];
-                a0 += w * a; a1 += w * b; a2 += w * a * a; a3 += w * b * b; a4 += w * a * b;
-            }
-            s.h[0][r][c] = a0; s.h[1][r][c] = a1; s.h[2][r][c] = a2; s.h[3][r][c] = a3; s.h[4][r][c] = a4;
-        }
-        __syncthreads();
-        // 3. vertical pass -> SSIM map and its partial derivatives on the tile + R halo
-        for (int i = tid; i < H1 * W1; i += THREADS) {
-            const int r = i / W1, c = i - r * W1;
-            const int gy = y0 - R + r, gx = x0 - R + c;
-            float dmu = 0.f, d11 = 0.f, d12 = 0.f;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+            for (int t = 0; t < 13; ++t) { a[t] = s.x[r][c + t]; b[t] = s.y[r][c + t]; }
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
 #pragma unroll
                 for (int t = 0; t < TAPS; ++t) {
-                    const float w = g[t];
-                    mu1 += w * s.h[0][r + t][c]; mu2 += w * s.h[1][r + t][c]; e11 += w * s.h[2][r + t][c];
-                    e22 += w * s.h[3][r + t][c]; e12 += w * s.h[4][r + t][c];
+                    const float w = g[t], u = a[o + t], v = b[o + t];
+                    a0 += w * u; a1 += w * v; a2 += w * u * u; a3 += w * v * v; a4 += w * u * v;
                 }
-                const float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * (e12 - mu1 * mu2) + C2;
-                const float B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = (e11 - mu1 * mu1) + (e22 - mu2 * mu2) + C2;
-                const float ib = 1.0f / (B1 * B2);
-                const float S = A1 * A2 * ib;
-                dmu = 2.f * mu2 * (A2 - A1) * ib - 2.f * mu1 * S / B1 + 2.f * mu1 * S / B2;
-                d11 = -S / B2;
-                d12 = 2.f * A1 * ib;
-                if (r >= R && r < R + TH && c >= R && c < R + TW) ssim_acc += S;
+                s.h[0][r][c + o] = a0; s.h[1][r][c + o] = a1; s.h[2][r][c + o] = a2; s.h[3][r][c + o] = a3; s.h[4][r][c + o] = a4;
             }
-            s.p[0][r][c] = dmu; s.p[1][r][c] = d11; s.p[2][r][c] = d12;
         }
         __syncthreads();
-        // 4. horizontal pass of the three derivative maps (into the h buffer, which is free now)
+        // 3. vertical pass -> SSIM map and its partial derivatives on the tile + R halo: 3 rows per thread
+        constexpr int G3 = 3, NG3 = (H1 + G3 - 1) / G3;
+        for (int i = tid; i < NG3 * W1; i += THREADS) {
+            const int rg = i / W1, c = i - rg * W1, r0 = rg * G3;
+            float v[5][G3 + 10];
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+#pragma unroll
+                for (int t = 0; t < G3 + 10; ++t) v[k][t] = s.h[k][r0 + t][c];
+#pragma unroll
+            for (int o = 0; o < G3; ++o) {
+                const int r = r0 + o;
+                if (r >= H1) break;
+                const int gy = y0 - R + r, gx = x0 - R + c;
+                float dmu = 0.f, d11 = 0.f, d12 = 0.f;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                    float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+                    for (int t = 0; t < TAPS; ++t) {
+                        const float w = g[t];
+                        mu1 += w * v[0][o + t]; mu2 += w * v[1][o + t]; e11 += w * v[2][o + t]; e22 += w * v[3][o + t];
+                        e12 += w * v[4][o + t];
+                    }
+                    const float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * (e12 - mu1 * mu2) + C2;
+                    const float B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = (e11 - mu1 * mu1) + (e22 - mu2 * mu2) + C2;
+                    const float ib = 1.0f / (B1 * B2);
+                    const float S = A1 * A2 * ib;
+                    dmu = 2.f * mu2 * (A2 - A1) * ib - 2.f * mu1 * S / B1 + 2.f * mu1 * S / B2;
+                    d11 = -S / B2;
+                    d12 = 2.f * A1 * ib;
+                    if (r >= R && r < R + TH && c >= R && c < R + TW) ssim_acc += S;
+                }
+                s.p[0][r][c] = dmu; s.p[1][r][c] = d11; s.p[2][r][c] = d12;
+            }
+        }
+        __syncthreads();
+        // 4. horizontal pass of the three derivative maps (into the h buffer, which is free now): 4 outputs per thread
         float(*q)[H1][TW] = reinterpret_cast<float(*)[H1][TW]>(&s.h[0][0][0]);
-        for (int i = tid; i < H1 * TW; i += THREADS) {
-            const int r = i / TW, c = i - r * TW;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int i = tid; i < H1 * (TW / 4); i += THREADS) {
+            const int r = i / (TW / 4), c = (i - r * (TW / 4)) * 4;
+            float v[3][14];
 #pragma unroll
-            for (int t = 0; t < TAPS; ++t) {
-                const float w = g[t];
-                a0 += w * s.p[0][r][c + t]; a1 += w * s.p[1][r][c + t]; a2 += w * s.p[2][r][c + t];
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int t = 0; t < 14; ++t) v[k][t] = s.p[k][r][c + t];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) { const float w = g[t]; a0 += w * v[0][o + t]; a1 += w * v[1][o + t]; a2 += w * v[2][o + t]; }
+                q[0][r][c + o] = a0; q[1][r][c + o] = a1; q[2][r][c + o] = a2;
             }
-            q[0][r][c] = a0; q[1][r][c] = a1; q[2][r][c] = a2;
         }
         __syncthreads();
-        // 5. vertical pass + L1 term -> gradient of this channel
-        for (int i = tid; i < TH * TW; i += THREADS) {
-            const int r = i / TW, c = i - r * TW;
-            const int gy = y0 + r, gx = x0 + c;
-            if (gy < H && gx < W) {
-                float cm = 0.f, c11 = 0.f, c12 = 0.f;
+        // 5. vertical pass + L1 term -> gradient of this channel: 2 rows per thread
+        for (int i = tid; i < (TH / 2) * TW; i += THREADS) {
+            const int rg = i / TW, c = i - rg * TW, r0 = rg * 2;
+            float v[3][12];
 #pragma unroll
-                for (int t = 0; t < TAPS; ++t) {
-                    const float w = g[t];
-                    cm += w * q[0][r + t][c]; c11 += w * q[1][r + t][c]; c12 += w * q[2][r + t][c];
-                }
-                const float a = s.x[r + 2 * R][c + 2 * R], b = s.y[r + 2 * R][c + 2 * R];
-                const float d = a - b;
-                l1_acc += fabsf(d);
-                if (grad) {
-                    const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-                    grad[img + ((int64_t)gy * W + gx) * 3 + ch] = inv_n * (l1w * sgn - sw * (cm + 2.f * a * c11 + b * c12));
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int t = 0; t < 12; ++t) v[k][t] = q[k][r0 + t][c];
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                const int r = r0 + o, gy = y0 + r, gx = x0 + c;
+                if (gy < H && gx < W) {
+                    float cm = 0.f, c11 = 0.f, c12 = 0.f;
+#pragma unroll
+                    for (int t = 0; t < TAPS; ++t) { const float w = g[t]; cm += w * v[0][o + t]; c11 += w * v[1][o + t]; c12 += w * v[2][o + t]; }
+                    const float a = s.x[r + 2 * R][c + 2 * R], b = s.y[r + 2 * R][c + 2 * R];
+                    const float d = a - b;
+                    l1_acc += fabsf(d);
+                    if (grad) {
+                        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+                        grad[img + ((int64_t)gy * W + gx) * 3 + ch] = inv_n * (l1w * sgn - sw * (cm + 2.f * a * c11 + b * c12));
+                    }
                 }
             }
         }
