@@ -14,7 +14,8 @@
 //   dS/dmu1 = 2 mu2 (A2 - A1) / (B1 B2) - 2 mu1 S / B1 + 2 mu1 S / B2,   dS/dE11 = -S / B2,   dS/dE12 = 2 A1 / (B1 B2),
 //   d(sum S)/dx(q) = (w * dS/dmu1)(q) + 2 x(q) (w * dS/dE11)(q) + y(q) (w * dS/dE12)(q)     (w is symmetric).
 //
-// One workgroup per 32 x 16 output tile and image; the three channels are processed one after the other through the
+// One workgroup per 16 x 16 output tile and image (40 KB of LDS: four workgroups per CU; 32 x 16 tiles needed 62 KB and
+// ran at two per CU, latency-bound); the three channels are processed one after the other through the
 // same LDS buffers: inputs with a 10-pixel halo, five horizontally filtered planes, the three partial-derivative maps
 // with a 5-pixel halo, their horizontally filtered planes.  Sums go to 64 shards (same-address atomics serialise).
 #include <cstdio>
@@ -25,17 +26,27 @@
 
 namespace {
 
-constexpr int TW = 32, TH = 16, R = 5, TAPS = 11;
-constexpr int W0 = TW + 4 * R, H0 = TH + 4 * R;      // input region   52 x 36
-constexpr int W1 = TW + 2 * R, H1 = TH + 2 * R;      // map region     42 x 26
+constexpr int TW = 16, TH = 16, R = 5, TAPS = 11;
+constexpr int W0 = TW + 4 * R, H0 = TH + 4 * R;      // input region   36 x 36
+constexpr int W1 = TW + 2 * R, H1 = TH + 2 * R;      // map region     26 x 26
+constexpr int G2 = (W1 % 3 == 0) ? 3 : 2;            // outputs per thread in the first horizontal pass
+static_assert(W1 % G2 == 0 && TW % 4 == 0 && TH % 2 == 0, "tile shape vs register blocking");
 constexpr int THREADS = 256, SHARDS = 64;
 
-constexpr int W0P = W0 + 4;      // row pitch of the input planes (register-blocked passes may read a few columns past W0)
+constexpr int W0P = W0 + 5;      // odd row pitch of the input planes (41): rows map to distinct banks; also read slack
+
+// LDS access patterns.  Horizontal passes: lanes run over ROWS (row index fastest), every lane reads G + 10 consecutive
+// words of its own row and writes G words; with odd row pitches (41, 29) consecutive rows start on different banks, so both
+// are conflict-free.  Vertical passes: lanes run over columns (26 or 16 per row group); the pitches (30, 25) put the next
+// row group on the following banks (3 * 30 = 26 mod 32: exact for the 26-column pass; 2 * 25 = 18: 2 lanes overlap).  With the
+// natural mapping and pitches (26, 16, column-fastest everywhere) 60 % of all LDS cycles were bank conflicts.
+constexpr int HP = 30, QP = 25, PP = 29;
+static_assert(HP >= W1 && QP >= TW && PP >= W1 + 2 && 3 * H1 * QP <= 5 * (H0 + 2) * HP, "plane pitches");
 
 struct LossLds {
     float x[H0][W0P], y[H0][W0P];
-    float h[5][H0 + 2][W1];      // horizontally filtered x, y, xx, yy, xy (+2 slack rows); later: q[3][H1][TW]
-    float p[3][H1][W1 + 2];      // dS/dmu1, dS/dE11, dS/dE12 (zero outside the image; +2 slack columns)
+    float h[5][H0 + 2][HP];      // horizontally filtered x, y, xx, yy, xy (+2 slack rows); later: q[3][H1][QP]
+    float p[3][H1][PP];          // dS/dmu1, dS/dE11, dS/dE12 (zero outside the image; slack columns)
 };
 // Every pass is register-blocked: a thread produces G consecutive outputs along the filter direction from G + 10 inputs
 // held in registers, so an output costs (G + 10) / G LDS reads per plane instead of 11.
@@ -62,28 +73,44 @@ __global__ __launch_bounds__(THREADS) void loss_kernel(const float* __restrict__
     gauss_taps(g);
     const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
     float l1_acc = 0.f, ssim_acc = 0.f;
+    // inputs with a 2R halo, zero outside the image (= the reference's zero padding); channel ch + 1 is fetched into
+    // registers while channel ch is being processed, so only the first fetch is exposed
+    constexpr int SLOTS = (H0 * W0 + THREADS - 1) / THREADS;
+    float ra[SLOTS], rb[SLOTS];
+    auto fetch = [&](int ch) {
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) {
+            const int i = tid + k * THREADS;
+            float a = 0.f, b = 0.f;
+            if (i < H0 * W0) {
+                const int r = i / W0, c = i - r * W0;
+                const int gy = y0 - 2 * R + r, gx = x0 - 2 * R + c;
+                if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                    const int64_t o = img + ((int64_t)gy * W + gx) * 3 + ch;
+                    a = pred[o]; b = target[o];
+                }
+            }
+            ra[k] = a; rb[k] = b;
+        }
+    };
+    fetch(0);
     for (int ch = 0; ch < 3; ++ch) {
         __syncthreads();
-        // 1. inputs with a 2R halo, zero outside the image (= the reference's zero padding)
-        for (int i = tid; i < H0 * W0; i += THREADS) {
-            const int r = i / W0, c = i - r * W0;
-            const int gy = y0 - 2 * R + r, gx = x0 - 2 * R + c;
-            float a = 0.f, b = 0.f;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                const int64_t o = img + ((int64_t)gy * W + gx) * 3 + ch;
-                a = pred[o]; b = target[o];
-            }
-            s.x[r][c] = a; s.y[r][c] = b;
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) {
+            const int i = tid + k * THREADS;
+            if (i < H0 * W0) { const int r = i / W0, c = i - r * W0; s.x[r][c] = ra[k]; s.y[r][c] = rb[k]; }
         }
         __syncthreads();
-        // 2. horizontal pass of the five products: 3 outputs per thread (W1 = 14 * 3)
-        for (int i = tid; i < H0 * (W1 / 3); i += THREADS) {
-            const int r = i / (W1 / 3), c = (i - r * (W1 / 3)) * 3;
-            float a[13], b[13];
+        if (ch < 2) fetch(ch + 1);
+        // 2. horizontal pass of the five products: G2 outputs per thread
+        for (int i = tid; i < H0 * (W1 / G2); i += THREADS) {
+            const int r = i % H0, c = (i / H0) * G2;                       // rows fastest across lanes
+            float a[G2 + 10], b[G2 + 10];
 #pragma unroll
-            for (int t = 0; t < 13; ++t) { a[t] = s.x[r][c + t]; b[t] = s.y[r][c + t]; }
+            for (int t = 0; t < G2 + 10; ++t) { a[t] = s.x[r][c + t]; b[t] = s.y[r][c + t]; }
 #pragma unroll
-            for (int o = 0; o < 3; ++o) {
+            for (int o = 0; o < G2; ++o) {
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
 #pragma unroll
                 for (int t = 0; t < TAPS; ++t) {
@@ -131,9 +158,9 @@ __global__ __launch_bounds__(THREADS) void loss_kernel(const float* __restrict__
         }
         __syncthreads();
         // 4. horizontal pass of the three derivative maps (into the h buffer, which is free now): 4 outputs per thread
-        float(*q)[H1][TW] = reinterpret_cast<float(*)[H1][TW]>(&s.h[0][0][0]);
+        float(*q)[H1][QP] = reinterpret_cast<float(*)[H1][QP]>(&s.h[0][0][0]);
         for (int i = tid; i < H1 * (TW / 4); i += THREADS) {
-            const int r = i / (TW / 4), c = (i - r * (TW / 4)) * 4;
+            const int r = i % H1, c = (i / H1) * 4;                        // rows fastest across lanes
             float v[3][14];
 #pragma unroll
             for (int k = 0; k < 3; ++k)

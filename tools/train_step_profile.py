@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""One training-style step on the benchmark scene: fused render -> fused L1+SSIM loss -> backward (diagnostic timing)."""
+import importlib, sys, time, torch
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+import bench
+PKG = "3d-gaussian-splatting-for-novel-view-synthesis_amd"
+gs = importlib.import_module(PKG); ops = importlib.import_module(PKG + ".ops"); losses = importlib.import_module(PKG + ".losses")
+params, cam = bench.synthetic_scene(3)
+dev = torch.device("cuda:0")
+p = {k: v.to(dev).requires_grad_(True) for k, v in params.items()}
+args = [p[k] for k in bench.NAMES] + [torch.eye(4, device=dev), cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"]]
+gt = torch.rand(cam["H"], cam["W"], 3, device=dev)
+def step():
+    for q in p.values(): q.grad = None
+    img = gs.render_gaussians(*args)
+    total = losses._LossFn.apply(img, gt, 0.8, 0.2)[2]
+    total.backward()
+for _ in range(3): step()
+t = ops.StageTimer(); ops.set_stage_timer(t)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+for _ in range(n): step()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n * 1e3
+ops.set_stage_timer(None)
+print(f"render + loss training step: {dt:.3f} ms", {k: round(v[1] / v[0], 3) for k, v in t.totals_ms().items()})
