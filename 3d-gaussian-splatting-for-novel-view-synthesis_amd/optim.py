@@ -1,0 +1,108 @@
+"""Optimiser step of the reference's training loop on the MI355X ("next" row 2).
+
+Mirrors the call sites of scripts/train.py: `optim.Adam([...six groups...], lr=lr, eps=1e-15)` (:394-401), the position
+learning-rate schedule (:446-457), `clip_grad_norm_(model.pos, max_norm=1.0)` (:536) and `optimizer.step()` (:538).
+`GaussianAdam` takes torch-style param groups; `step()` runs one fused HIP kernel per tensor (csrc/gsplat_optim.hip); the
+clip coefficient is computed and applied on the device, so a training step has no host synchronisation here.
+"""
+import ctypes as C
+
+import torch
+
+from . import _abi
+from .ops import _p, _stage, _stream_ptr
+
+
+def position_lr(iteration, position_lr_init=0.00016, position_lr_final=0.0000016, position_lr_delay_mult=0.01,
+                position_lr_max_steps=30000):
+    """Exponential decay with the initial x0.01 delay phase (scripts/train.py:446-457)."""
+    if iteration < position_lr_max_steps:
+        lr = position_lr_init * (position_lr_final / position_lr_init) ** (iteration / position_lr_max_steps)
+    else:
+        lr = position_lr_final
+    if iteration < position_lr_delay_mult * position_lr_max_steps:
+        lr *= 0.01
+    return lr
+
+
+def reference_param_groups(model, position_lr_init=0.00016, feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005,
+                           rotation_lr=0.001):
+    """The six groups of scripts/train.py:394-401; `model` has pos, opacity_raw, f_dc, f_rest, scale_raw, q_raw."""
+    return [{'params': [model.pos], 'lr': position_lr_init, 'name': 'pos'},
+            {'params': [model.opacity_raw], 'lr': opacity_lr, 'name': 'opacity'},
+            {'params': [model.f_dc], 'lr': feature_lr, 'name': 'f_dc'},
+            {'params': [model.f_rest], 'lr': feature_lr / 20.0, 'name': 'f_rest'},
+            {'params': [model.scale_raw], 'lr': scaling_lr, 'name': 'scale'},
+            {'params': [model.q_raw], 'lr': rotation_lr, 'name': 'rotation'}]
+
+
+class GaussianAdam:
+    """torch.optim.Adam (amsgrad off, no weight decay) restricted to what the reference uses, fused per tensor.
+
+    `clip` = (parameter tensor, max_norm): clip_grad_norm_ on that tensor before the step, fused into its update."""
+
+    def __init__(self, param_groups, lr=0.01, betas=(0.9, 0.999), eps=1e-15):
+        self.param_groups = []
+        for g in param_groups:
+            g = dict(g)
+            g.setdefault('lr', lr)
+            g['params'] = list(g['params'])
+            self.param_groups.append(g)
+        self.betas, self.eps = betas, eps
+        self.state = {}
+        self._clip_buf = None
+
+    def zero_grad(self, set_to_none=True):
+        for g in self.param_groups:
+            for p in g['params']:
+                if set_to_none:
+                    p.grad = None
+                elif p.grad is not None:
+                    p.grad.zero_()
+
+    def _state(self, p):
+        st = self.state.get(p)
+        if st is None:
+            st = self.state[p] = {'step': 0, 'exp_avg': torch.zeros_like(p, memory_format=torch.contiguous_format),
+                                  'exp_avg_sq': torch.zeros_like(p, memory_format=torch.contiguous_format)}
+        return st
+
+    @torch.no_grad()
+    def clip_grad_norm_(self, param, max_norm=1.0):
+        """Device-side clip_grad_norm_ for one tensor; returns the [coef, norm] device tensor (no host read)."""
+        lib = _abi.lib()
+        g = param.grad
+        if g is None:
+            return None
+        if not (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous()):
+            raise RuntimeError("GaussianAdam needs contiguous fp32 GPU gradients (there is no CPU fallback)")
+        dev = g.device
+        with torch.cuda.device(dev):
+            if self._clip_buf is None or self._clip_buf[0].device != dev:
+                self._clip_buf = (torch.empty(2, dtype=torch.float32, device=dev),
+                                  torch.empty(lib.gsplat_clip_scratch_bytes(), dtype=torch.uint8, device=dev))
+            out, scratch = self._clip_buf
+            _abi.check(lib.gsplat_clip_grad_norm(g.numel(), _p(g), float(max_norm), _p(out), _p(scratch), _stream_ptr(dev)),
+                       "gsplat_clip_grad_norm")
+        self._pending_clip = (param, out)
+        return out
+
+    @torch.no_grad()
+    def step(self):
+        lib = _abi.lib()
+        pending = getattr(self, "_pending_clip", None)
+        with _stage("adam"):
+            for g in self.param_groups:
+                for p in g['params']:
+                    if p.grad is None:
+                        continue
+                    if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
+                        raise RuntimeError("GaussianAdam needs contiguous fp32 GPU parameters (there is no CPU fallback)")
+                    st = self._state(p)
+                    st['step'] += 1
+                    scale = pending[1] if pending is not None and pending[0] is p else None
+                    with torch.cuda.device(p.device):
+                        _abi.check(lib.gsplat_adam_step(p.numel(), _p(p), _p(p.grad), _p(st['exp_avg']), _p(st['exp_avg_sq']),
+                                                        float(g['lr']), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                                        int(st['step']), _p(scale), _stream_ptr(p.device)), "gsplat_adam_step")
+        self._pending_clip = None

@@ -161,6 +161,17 @@ int64_t gsplat_loss_scratch_bytes(void);
 int gsplat_loss(const float* pred, const float* target, int64_t batch, int32_t H, int32_t W, float lambda_l1,
                 float lambda_ssim, float* values, float* grad_pred, void* scratch, void* stream);
 
+/* ---- next row 2: the optimiser step of scripts/train.py:394-401, 536-538 ---------------------
+ * gsplat_clip_grad_norm = torch.nn.utils.clip_grad_norm_ on one tensor: coef_and_norm[2] (device) receives
+ * (min(1, max_norm / (||grad|| + 1e-6)), ||grad||); nothing is scaled yet and nothing is read back to the host.
+ * gsplat_adam_step = one torch.optim.Adam update (amsgrad off, no weight decay) of one flat fp32 tensor at 1-based
+ * `step`; if grad_scale (device scalar, e.g. the clip coefficient) is given the gradient is multiplied by it in place
+ * first, exactly like clip_grad_norm_ followed by optimizer.step().                                                  */
+int64_t gsplat_clip_scratch_bytes(void);
+int gsplat_clip_grad_norm(int64_t n, const float* grad, float max_norm, float* coef_and_norm, void* scratch, void* stream);
+int gsplat_adam_step(int64_t n, float* param, float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                     float beta2, float eps, int32_t step, const float* grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -251,6 +251,56 @@ def gen_loss():
     save("loss", **out)
 
 
+def gen_optim():
+    """Next-row fixture: the optimiser step at the reference's call sites (scripts/train.py:394-401 Adam groups with
+    eps = 1e-15, :446-457 position-LR schedule, :536 clip_grad_norm_(pos, 1.0), :538 optimizer.step()), run with
+    torch.optim.Adam itself in float64 for three iterations on small tensors."""
+    print("optim")
+    rng = np.random.default_rng(511)
+    n = 37
+    shapes = {"pos": (n, 3), "opacity_raw": (n,), "f_dc": (n, 3), "f_rest": (n, 45), "scale_raw": (n, 3), "q_raw": (n, 4)}
+    init = {k: rng.normal(0, 1, s).astype(np.float32) for k, s in shapes.items()}
+    iters = [0, 1, 299, 300, 29999, 30000]        # delay phase, its end, decay end
+    grads = {k: np.stack([rng.normal(0, 3.0 if k == "pos" else 1.0, s) * (10.0 ** rng.integers(-3, 1)) for _ in iters]).astype(np.float32)
+             for k, s in shapes.items()}
+    P = {k: torch.nn.Parameter(_t(init[k], torch.float64)) for k in shapes}
+    position_lr_init, position_lr_final, delay_mult, max_steps = 0.00016, 0.0000016, 0.01, 30000
+    feature_lr, opacity_lr, scaling_lr, rotation_lr = 0.0025, 0.05, 0.005, 0.001
+    opt = torch.optim.Adam([
+        {'params': [P["pos"]], 'lr': position_lr_init, 'name': 'pos'},
+        {'params': [P["opacity_raw"]], 'lr': opacity_lr, 'name': 'opacity'},
+        {'params': [P["f_dc"]], 'lr': feature_lr, 'name': 'f_dc'},
+        {'params': [P["f_rest"]], 'lr': feature_lr / 20.0, 'name': 'f_rest'},
+        {'params': [P["scale_raw"]], 'lr': scaling_lr, 'name': 'scale'},
+        {'params': [P["q_raw"]], 'lr': rotation_lr, 'name': 'rotation'},
+    ], lr=0.01, eps=1e-15)
+    out = {"iters": np.array(iters)}
+    lrs, norms = [], []
+    for j, it in enumerate(iters):
+        if it < max_steps:
+            plr = position_lr_init * (position_lr_final / position_lr_init) ** (it / max_steps)
+        else:
+            plr = position_lr_final
+        if it < delay_mult * max_steps:
+            plr *= 0.01
+        opt.param_groups[0]['lr'] = plr
+        lrs.append(plr)
+        for k in shapes:
+            P[k].grad = _t(grads[k][j], torch.float64)
+        norms.append(float(torch.nn.utils.clip_grad_norm_(P["pos"], max_norm=1.0)))
+        opt.step()
+        for k in shapes:
+            out[f"after{j}_{k}"] = P[k].detach().numpy().copy()
+        out[f"clipped{j}_pos"] = P["pos"].grad.numpy().copy()
+    out["pos_lr"] = np.array(lrs)
+    out["pos_grad_norm"] = np.array(norms)
+    for k in shapes:
+        out["init_" + k] = init[k]
+        out["grads_" + k] = grads[k]
+    print("  position lr per iteration:", lrs, " pos grad norms:", [round(x, 3) for x in norms])
+    save("optim", **out)
+
+
 def gen_config1():
     """G12: config 1 at full size (10k Gaussians, 256x256, f_rest = 0): image + gradient digests."""
     name = "g13_config1_full"
@@ -286,3 +336,5 @@ if __name__ == "__main__":
         gen_config1()
     if not want or "loss" in want:
         gen_loss()
+    if not want or "optim" in want:
+        gen_optim()
