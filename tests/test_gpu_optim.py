@@ -45,7 +45,8 @@ def test_fused_adam_matches_torch_adam_at_the_reference_settings():
             got = getattr(m, k).detach().cpu().numpy()
             # parameters are O(1), one step moves them by ~lr: compare the accumulated movement
             moved = np.abs(ref - d["init_" + k]).max()
-            assert np.abs(got - ref).max() <= 2e-4 * moved + 2e-7, (k, j, np.abs(got - ref).max(), moved)
+            # + a few fp32 ulps of the parameter itself (the position LR is 1.6e-6: steps are close to the fp32 resolution)
+            assert np.abs(got - ref).max() <= 2e-4 * moved + 4 * 1.2e-7 * max(1.0, np.abs(ref).max()), (k, j, np.abs(got - ref).max(), moved)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         cpu = M()
         for k in NAMES:
