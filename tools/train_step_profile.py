@@ -5,21 +5,32 @@ sys.path.insert(0, __file__.rsplit("/", 2)[0])
 import bench
 PKG = "3d-gaussian-splatting-for-novel-view-synthesis_amd"
 gs = importlib.import_module(PKG); ops = importlib.import_module(PKG + ".ops"); losses = importlib.import_module(PKG + ".losses")
+optim = importlib.import_module(PKG + ".optim")
 params, cam = bench.synthetic_scene(3)
 dev = torch.device("cuda:0")
 p = {k: v.to(dev).requires_grad_(True) for k, v in params.items()}
 args = [p[k] for k in bench.NAMES] + [torch.eye(4, device=dev), cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"]]
 gt = torch.rand(cam["H"], cam["W"], 3, device=dev)
+class M: pass
+m = M()
+for k, v in p.items(): setattr(m, k, v)
+opt = optim.GaussianAdam(optim.reference_param_groups(m), lr=0.01, eps=1e-15)
+tadam = torch.optim.Adam(optim.reference_param_groups(m), lr=0.01, eps=1e-15)
+USE_TORCH_ADAM = "--torch-adam" in sys.argv
 def step():
     for q in p.values(): q.grad = None
     img = gs.render_gaussians(*args)
     total = losses._LossFn.apply(img, gt, 0.8, 0.2)[2]
     total.backward()
+    if USE_TORCH_ADAM:
+        torch.nn.utils.clip_grad_norm_(m.pos, 1.0); tadam.step()
+    else:
+        opt.clip_grad_norm_(m.pos, 1.0); opt.step()
 for _ in range(3): step()
 t = ops.StageTimer(); ops.set_stage_timer(t)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 20
 for _ in range(n): step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n * 1e3
 ops.set_stage_timer(None)
-print(f"render + loss training step: {dt:.3f} ms", {k: round(v[1] / v[0], 3) for k, v in t.totals_ms().items()})
+print(f"render + loss + clip + Adam training step ({'torch Adam' if USE_TORCH_ADAM else 'fused Adam'}): {dt:.3f} ms", {k: round(v[1] / v[0], 3) for k, v in t.totals_ms().items()})
