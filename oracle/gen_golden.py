@@ -301,6 +301,42 @@ def gen_optim():
     save("optim", **out)
 
 
+def gen_harness():
+    """Next-row fixtures: create_orbit_trajectory (scripts/render_trained.py:28-75) outputs, and a checkpoint + the six
+    loose tensor files written by the reference's own GaussianModel.save_checkpoint / training-loop lines."""
+    print("harness")
+    import importlib.util
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, "scripts", name + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+    rt = load("render_trained")
+    out = {}
+    for tag, args in (("a", dict(center=[0.3, -1.2, 0.5], radius=3.0, num_frames=12, elevation=0.0)),
+                      ("b", dict(center=[0.0, 0.0, 0.0], radius=4.5, num_frames=7, elevation=0.4))):
+        out["orbit_" + tag] = rt.create_orbit_trajectory(**args)
+        out["orbit_args_" + tag] = np.array(list(args["center"]) + [args["radius"], args["num_frames"], args["elevation"]])
+    save("harness", **out)
+    tr = load("train")
+    rng = np.random.default_rng(611)
+    n = 11
+    model = object.__new__(tr.GaussianModel)              # only the tensors matter to save_checkpoint
+    shapes = {"pos": (n, 3), "opacity_raw": (n,), "f_dc": (n, 3), "f_rest": (n, 45), "scale_raw": (n, 3), "q_raw": (n, 4)}
+    for k, sh in shapes.items():
+        setattr(model, k, torch.nn.Parameter(_t(rng.normal(0, 1, sh).astype(np.float32), torch.float32)))
+    ck_dir = os.path.join(OUT, "ref_checkpoint")
+    os.makedirs(ck_dir, exist_ok=True)
+    model.save_checkpoint(os.path.join(ck_dir, "checkpoint_001000.pt"), 1000)
+    # the loose files of scripts/train.py:590-597
+    it = 2000
+    torch.save(model.pos.cpu(), os.path.join(ck_dir, f"pos_{it}.pt")); torch.save(model.opacity_raw.cpu(), os.path.join(ck_dir, f"opacity_raw_{it}.pt"))
+    torch.save(model.f_dc.cpu(), os.path.join(ck_dir, f"f_dc_{it}.pt")); torch.save(model.f_rest.cpu(), os.path.join(ck_dir, f"f_rest_{it}.pt"))
+    torch.save(model.scale_raw.cpu(), os.path.join(ck_dir, f"scale_raw_{it}.pt")); torch.save(model.q_raw.cpu(), os.path.join(ck_dir, f"q_rot_{it}.pt"))
+    np.savez(os.path.join(ck_dir, "expected.npz"), **{k: getattr(model, k).detach().numpy() for k in shapes})
+    print("  wrote", ck_dir)
+
+
 def gen_config1():
     """G12: config 1 at full size (10k Gaussians, 256x256, f_rest = 0): image + gradient digests."""
     name = "g13_config1_full"
@@ -338,3 +374,5 @@ if __name__ == "__main__":
         gen_loss()
     if not want or "optim" in want:
         gen_optim()
+    if not want or "harness" in want:
+        gen_harness()
