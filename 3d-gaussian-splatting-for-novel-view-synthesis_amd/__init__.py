@@ -17,6 +17,7 @@ from . import losses  # noqa: E402,F401  (L1 + SSIM loss, SURVEY §8f next row 1
 from .losses import compute_loss  # noqa: E402,F401
 from . import optim  # noqa: E402,F401  (fused Adam + clip)
 from . import harness  # noqa: E402,F401  (orbit, FPS meter, checkpoint formats: SURVEY §8f next row 3)
+from . import data  # noqa: E402,F401  (on-disk layout + Gaussian initialisation: SURVEY §8f next row 4)
 from . import dp  # noqa: E402,F401  (data-parallel-by-view helpers)
 
 __all__ = [

@@ -337,6 +337,47 @@ def gen_harness():
     print("  wrote", ck_dir)
 
 
+def gen_data():
+    """Next-row fixtures: a tiny scene in the reference's on-disk layout, and what the reference's own loaders return for
+    it (GaussianDataset, load_point_cloud, initialize_gaussians_from_pointcloud; gaussian_splatting/data_loader.py)."""
+    print("data")
+    from PIL import Image
+    dl = sys.modules.get("gaussian_splatting.data_loader") or __import__("gaussian_splatting.data_loader", fromlist=["x"])
+    rng = np.random.default_rng(711)
+    root = os.path.join(OUT, "ref_dataset")
+    os.makedirs(os.path.join(root, "images"), exist_ok=True)
+    for i in range(3):
+        Image.fromarray(rng.integers(0, 256, (12, 18, 3), dtype=np.uint8)).save(os.path.join(root, "images", f"{i:04d}.png"))
+    np.save(os.path.join(root, "cam_meta.npy"), {'fx': 20.5, 'fy': 21.0, 'cx': 9.25, 'cy': 5.75, 'height': 12, 'width': 18}, allow_pickle=True)
+    np.save(os.path.join(root, "poses.npy"), np.stack([scenes._camera(rng) for _ in range(3)]))
+    pts = rng.normal(0, 2, (40, 3))
+    pts[5] = [np.nan, 0, 0]; pts[9] = [5000.0, 1, 1]
+    with open(os.path.join(root, "pointcloud.ply"), "w") as f:
+        f.write(f"ply\nformat ascii 1.0\nelement vertex {len(pts)}\nproperty float x\nproperty float y\nproperty float z\nend_header\n")
+        for x, y, z in pts:
+            f.write(f"{x:.7g} {y:.7g} {z:.7g}\n")
+    out = {}
+    for sf in (1.0, 0.5):
+        ds = dl.GaussianDataset(root, scale_factor=sf)
+        tag = "full" if sf == 1.0 else "half"
+        for i in range(len(ds)):
+            smp = ds[i]
+            out[f"{tag}_image{i}"] = smp['image'].numpy()
+            out[f"{tag}_c2w{i}"] = smp['c2w'].numpy()
+            out[f"{tag}_intr{i}"] = np.array([smp['fx'], smp['fy'], smp['cx'], smp['cy'], smp['H'], smp['W']], dtype=np.float64)
+    cloud = dl.load_point_cloud(os.path.join(root, "pointcloud.ply"))
+    out["cloud"] = cloud.numpy()
+    torch.manual_seed(5)
+    init = dl.initialize_gaussians_from_pointcloud(cloud, num_sh_bands=3)
+    for k, v in init.items():
+        out["init_" + k] = v.numpy()
+    rgbpts = torch.cat([cloud, torch.rand(len(cloud), 3) * 255], 1)
+    out["rgb_points"] = rgbpts.numpy()
+    torch.manual_seed(6)
+    out["init_rgb_f_dc"] = dl.initialize_gaussians_from_pointcloud(rgbpts)["f_dc"].numpy()
+    save("data", **out)
+
+
 def gen_config1():
     """G12: config 1 at full size (10k Gaussians, 256x256, f_rest = 0): image + gradient digests."""
     name = "g13_config1_full"
@@ -376,3 +417,5 @@ if __name__ == "__main__":
         gen_optim()
     if not want or "harness" in want:
         gen_harness()
+    if not want or "data" in want:
+        gen_data()
