@@ -19,6 +19,8 @@ from . import optim  # noqa: E402,F401  (fused Adam + clip, SURVEY §8f next row
 from . import harness  # noqa: E402,F401  (orbit, FPS meter, checkpoint formats: SURVEY §8f next row 3)
 from . import data  # noqa: E402,F401  (on-disk layout + Gaussian initialisation: SURVEY §8f next row 4)
 from . import dp  # noqa: E402,F401  (data-parallel-by-view helpers)
+from . import model  # noqa: E402,F401  (GaussianModel: densify / prune / opacity reset)
+from . import training  # noqa: E402,F401  (one training iteration of the reference's loop on the fused pieces)
 
 __all__ = [
     'build_sigma_from_params', 'quat_to_rotmat', 'evaluate_sh', 'HARMONICS', 'render', 'project_points', 'inv2x2',

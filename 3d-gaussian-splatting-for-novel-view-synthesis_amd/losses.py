@@ -63,3 +63,11 @@ def ssim_loss(pred, target, window_size=11, size_average=True):
     if window_size != 11 or not size_average:
         raise NotImplementedError("the fused kernel implements the reference defaults: window_size=11, size_average=True")
     return _LossFn.apply(pred, target, 0.0, 1.0)[2].to(pred.dtype)
+
+
+def compute_loss_device(pred, target, lambda_l1=0.8, lambda_ssim=0.2):
+    """compute_loss without the host read: returns (total_loss, values) with values = device tensor [l1, 1 - ssim, total]
+    (the training step keeps the loss on the GPU and reads it only when the caller logs it)."""
+    v = _LossFn.apply(pred, target, lambda_l1, lambda_ssim)
+    total = v[2]
+    return (total if pred.dtype == torch.float32 else total.to(pred.dtype)), v.detach()

@@ -1,0 +1,123 @@
+"""One training iteration of the reference's loop on the MI355X ("next" row 2: optimiser / training step).
+
+Follows scripts/train.py:446-569 statement by statement, on the fused pieces of this package:
+
+    position learning rate (:446-457)          optim.position_lr
+    zero_grad (:460)                           GaussianAdam.zero_grad
+    per view of the batch (:471-527)           ops.render_gaussians (covariance build + SH folded in; the reference's
+                                               build_sigma + evaluate_sh + render) -> losses.compute_loss_device,
+                                               loss / batch size, accumulated
+    backward (:530)                            per view, gradients accumulate in .grad (same sum, frees each view's buffers)
+    [data parallel]                            dp.allreduce_gradients: sum over ranks (not in the reference)
+    clip_grad_norm_(pos, 1.0) + step (:536-538) GaussianAdam.clip_grad_norm_ / .step (device-side coefficient, no host sync)
+    densify / prune every `densification_interval` (:544-561)   model.GaussianModel.densify_and_prune + a fresh optimiser
+                                               with the CURRENT position learning rate, as there
+    opacity reset every `opacity_reset_interval` (:564-569)     GaussianModel.reset_opacity
+
+With data parallelism every rank holds the full model, renders its share of the batch's views and divides by the GLOBAL
+number of views; the split noise of densification comes from a generator seeded identically on all ranks, so the
+replicas stay bit-identical without a broadcast.
+"""
+from dataclasses import dataclass
+
+import torch
+import torch.distributed as dist
+
+from . import dp, losses, ops, optim
+
+
+@dataclass
+class TrainConfig:
+    """Hyper-parameters of scripts/train.py:222-251 (same names, same defaults)."""
+    iterations: int = 30000
+    lr: float = 0.01
+    position_lr_init: float = 0.00016
+    position_lr_final: float = 0.0000016
+    position_lr_delay_mult: float = 0.01
+    position_lr_max_steps: int = 30000
+    feature_lr: float = 0.0025
+    opacity_lr: float = 0.05
+    scaling_lr: float = 0.005
+    rotation_lr: float = 0.001
+    lambda_l1: float = 0.8
+    lambda_ssim: float = 0.2
+    densify_until_iter: int = 15000
+    densification_interval: int = 100
+    opacity_reset_interval: int = 3000
+    prune_opacity_threshold: float = 0.01
+    max_grad: float = 0.01
+    scale_threshold: float = 0.01
+    checkpoint_interval: int = 1000
+    densify_seed: int = 0
+
+
+class Trainer:
+    """Owns the optimiser of a GaussianModel and runs iterations.  `group`: torch.distributed group for data parallelism
+    by camera view (None = default group if initialised, else single process)."""
+
+    def __init__(self, model, config=None, group=None):
+        self.model = model
+        self.cfg = config or TrainConfig()
+        self.group = group
+        self.optimizer = self._new_optimizer(self.cfg.position_lr_init)
+        self._gen = None
+
+    def _new_optimizer(self, pos_lr):
+        c = self.cfg
+        groups = optim.reference_param_groups(self.model, position_lr_init=pos_lr, feature_lr=c.feature_lr,
+                                              opacity_lr=c.opacity_lr, scaling_lr=c.scaling_lr, rotation_lr=c.rotation_lr)
+        return optim.GaussianAdam(groups, lr=c.lr, eps=1e-15)
+
+    def _world(self):
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.group)
+        return 1
+
+    def _densify_generator(self, iteration):
+        # same stream of split noise on every rank: CPU generator keyed by (seed, iteration)
+        g = torch.Generator()
+        g.manual_seed(self.cfg.densify_seed * 1000003 + iteration)
+        return g
+
+    def step(self, iteration, views, global_views=None):
+        """One iteration on this rank's `views` (list of dicts with image [H,W,3], c2w [4,4], H, W, fx, fy, cx, cy — the
+        sample dict of data.GaussianDataset).  `global_views` = number of views of the whole batch over all ranks
+        (default: len(views) * world size).  Returns {'loss', 'l1', 'ssim'} as device scalars (this rank's share,
+        already divided by the global batch), 'gaussians', 'lr_pos', 'densified'."""
+        c, m = self.cfg, self.model
+        world = self._world()
+        n_global = global_views if global_views is not None else len(views) * world
+        pos_lr = optim.position_lr(iteration, c.position_lr_init, c.position_lr_final, c.position_lr_delay_mult,
+                                   c.position_lr_max_steps)
+        self.optimizer.param_groups[0]['lr'] = pos_lr
+        self.optimizer.zero_grad()
+        dev = m.pos.device
+        acc = torch.zeros(3, dtype=torch.float32, device=dev)
+        for v in views:
+            image_gt = torch.as_tensor(v['image']).to(dev)
+            c2w = torch.as_tensor(v['c2w'], dtype=torch.float32).to(dev)
+            rendered = ops.render_gaussians(m.pos, m.f_dc, m.f_rest, m.opacity_raw, m.scale_raw, m.q_raw, c2w,
+                                            int(v['H']), int(v['W']), float(v['fx']), float(v['fy']), float(v['cx']), float(v['cy']))
+            loss, vals = losses.compute_loss_device(rendered, image_gt, c.lambda_l1, c.lambda_ssim)
+            (loss / n_global).backward()
+            acc += vals / n_global
+        names = dp.PARAM_NAMES
+        for k in names:
+            p = getattr(m, k)
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        if world > 1:
+            dp.allreduce_gradients([getattr(m, k).grad for k in names], world_views=1, group=self.group)
+        self.optimizer.clip_grad_norm_(m.pos, max_norm=1.0)
+        self.optimizer.step()
+        densified = False
+        if iteration < c.densify_until_iter and iteration % c.densification_interval == 0:
+            grads = {'pos': m.pos.grad, 'opacity_raw': m.opacity_raw.grad}
+            m.densify_and_prune(grads, opacity_threshold=c.prune_opacity_threshold, max_grad=c.max_grad,
+                                scale_threshold=c.scale_threshold, generator=self._densify_generator(iteration))
+            self.optimizer = self._new_optimizer(pos_lr)
+            densified = True
+        if iteration % c.opacity_reset_interval == 0:
+            m.reset_opacity()
+        return {'loss': acc[2], 'l1': acc[0], 'ssim': acc[1], 'gaussians': m.get_num_gaussians(), 'lr_pos': pos_lr,
+                'densified': densified}

@@ -378,6 +378,58 @@ def gen_data():
     save("data", **out)
 
 
+def gen_densify():
+    """Next-row fixture: adaptive density control.  Runs the reference's own GaussianModel.densify_and_prune
+    (scripts/train.py:89-195) on CPU with torch.manual_seed fixed (the split draws randn_like), and the opacity-reset
+    expression of the training loop (scripts/train.py:564-569, inline code there, evaluated here with the same torch calls)."""
+    print("densify")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("train", os.path.join(REF, "scripts", "train.py"))
+    tr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tr)
+    rng = np.random.default_rng(711)
+    n = 60
+    shapes = {"pos": (n, 3), "opacity_raw": (n,), "f_dc": (n, 3), "f_rest": (n, 45), "scale_raw": (n, 3), "q_raw": (n, 4)}
+    init = {k: rng.normal(0, 1, s).astype(np.float32) for k, s in shapes.items()}
+    init["opacity_raw"] = rng.normal(-2.0, 3.0, n).astype(np.float32)          # a good share below sigmoid^-1(0.01) = -4.6
+    init["scale_raw"] = rng.normal(-5.1, 0.6, (n, 3)).astype(np.float32)       # max exp() on both sides of 0.01
+    gpos = (rng.normal(0, 1, (n, 3)) * 10.0 ** rng.integers(-4, 0, (n, 1))).astype(np.float32)   # norms on both sides of 0.01
+    gopa = rng.normal(0, 1, n).astype(np.float32)
+    out = {"init_" + k: v for k, v in init.items()}
+    out["grad_pos"], out["grad_opacity_raw"] = gpos, gopa
+    # name -> (kwargs, use grads)
+    cases = {
+        "split_only": (dict(opacity_threshold=0.01, max_grad=0.01, scale_threshold=1e-6), True),
+        "clone_only": (dict(opacity_threshold=0.01, max_grad=0.01, scale_threshold=10.0), True),
+        "prune_only": (dict(opacity_threshold=0.05, max_grad=1e9, scale_threshold=0.01), True),
+        "nothing": (dict(opacity_threshold=1e-9, max_grad=1e9, scale_threshold=0.01), True),
+        "no_grads": (dict(opacity_threshold=0.01, max_grad=0.01, scale_threshold=0.01), False),
+        "both": (dict(opacity_threshold=0.01, max_grad=0.01, scale_threshold=0.01), True),
+    }
+    for name, (kw, use_grads) in cases.items():
+        model = tr.GaussianModel({k: _t(v, torch.float32) for k, v in init.items()}, device="cpu")
+        grads = {"pos": _t(gpos, torch.float32), "opacity_raw": _t(gopa, torch.float32)} if use_grads else None
+        torch.manual_seed(1234)
+        try:
+            model.densify_and_prune(grads, **kw)
+            raised = ""
+        except Exception as e:                       # the reference's own failure when split and clone are both due
+            raised = type(e).__name__
+        out[f"{name}_kwargs"] = np.array([kw["opacity_threshold"], kw["max_grad"], kw["scale_threshold"]])
+        out[f"{name}_raised"] = np.array(raised)
+        for k in shapes:
+            out[f"{name}_{k}"] = getattr(model, k).detach().numpy().copy()
+        print(f"  {name}: {n} -> {model.get_num_gaussians()} Gaussians" + (f"  (reference raised {raised})" if raised else ""))
+    # opacity reset, scripts/train.py:564-569
+    o_raw = _t(init["opacity_raw"], torch.float32).clone()
+    opacity = torch.sigmoid(o_raw)
+    mask = opacity < 0.01
+    o_raw[mask] = torch.logit(torch.clamp(opacity[mask] + 0.01, 0, 1))
+    out["reset_opacity_raw"] = o_raw.numpy()
+    out["reset_count"] = np.array(int(mask.sum()))
+    save("densify", **out)
+
+
 def gen_config1():
     """G12: config 1 at full size (10k Gaussians, 256x256, f_rest = 0): image + gradient digests."""
     name = "g13_config1_full"
@@ -419,3 +471,5 @@ if __name__ == "__main__":
         gen_harness()
     if not want or "data" in want:
         gen_data()
+    if not want or "densify" in want:
+        gen_densify()
