@@ -13,7 +13,7 @@ GSPLAT_OK = 0
 GSPLAT_SCENE_OK = 0
 GSPLAT_SCENE_ALL_CULLED = 10
 GSPLAT_SCENE_ALL_OFFSCREEN = 11
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _F = C.POINTER(C.c_float)
 
@@ -39,7 +39,7 @@ class GaussianGrads(C.Structure):
 
 class Counts(C.Structure):
     _fields_ = [("n_survivors", C.c_int32), ("n_visible", C.c_int32), ("n_pairs", C.c_int64),
-                ("max_tiles_per_gaussian", C.c_int32), ("reserved", C.c_int32)]
+                ("max_tiles_per_gaussian", C.c_int32), ("reserved", C.c_int32), ("n_binned", C.c_int64)]
 
 
 _VP, _I64, _INT = C.c_void_p, C.c_int64, C.c_int
@@ -50,7 +50,7 @@ SIGNATURES = {
     "gsplat_abi_version": (_INT, []),
     "gsplat_last_error": (C.c_char_p, []),
     "gsplat_classify_counts": (_INT, [_PC]),
-    "gsplat_project_state_bytes": (_I64, [_I64]),
+    "gsplat_project_state_bytes": (_I64, [_I64, _PV]),
     "gsplat_project_scratch_bytes": (_I64, [_I64]),
     "gsplat_bin_state_bytes": (_I64, [_I64, _PV]),
     "gsplat_bin_scratch_bytes": (_I64, [_I64, _I64]),

@@ -16,8 +16,9 @@ struct u2 { uint32_t x, y; };
 // Projected record: ONE 64-byte line per Gaussian (the rasterizer gathers records by id; three separate 16-byte
 // streams cost three cache lines per gather), plus small per-Gaussian streams for the binning kernels:
 //   rec[i] = { (u, v, A11, A12), (A22, opacity, ex, ey), (r, g, b, depth z), (unused) }
-//   rect[i] = (tx0 | ty0 << 16, tx1 | ty1 << 16)   inclusive tile rectangle
-//   depth[i] = z                                   tiles[i] = tiles touched (0 = not visible)
+//   rect[i] = (bx0 | by0 << 16, bx1 | by1 << 16)   inclusive rectangle of half-tile lists (16 x 8 pixels each) binned
+//   depth[i] = z                                   tiles[i] = lists touched (0 = contributes to no pixel)
+//   ref_rect[i] (host check only) = the reference's own tile rectangle (F10), T x T tiles
 // (ex, ey) are the half-extents of {q <= chi_square_clip}: the rasterizer culls with them at staging time.
 struct alignas(64) Rec64 { f4 r0, r1, r2, pad; };
 
@@ -26,6 +27,8 @@ struct Records {
     u2* rect;
     float* depth;
     uint32_t* tiles;
+    u2* ref_rect;          // nullable
+    uint32_t* ref_tiles;   // nullable
 };
 
 GS_HD ViewK make_viewk(const gsplat_view& v) {
@@ -67,8 +70,10 @@ struct GaussIn {
 
 struct RecOut {             // what K1 stores for one Gaussian
     f4 r0, r1, r2;
-    u2 rect;
-    uint32_t tiles;
+    u2 rect;                // binned half-tile lists
+    uint32_t tiles;         // number of lists
+    u2 ref_rect;            // the reference's tile rectangle (F10)
+    uint32_t ref_tiles;     // its tile count: the reference's (tile, Gaussian) pairs (F11)
     int vis;
 };
 
@@ -98,6 +103,8 @@ GS_HD RecOut project_finish(const GaussIn& in, const Proj& o, bool fused, Coef c
     r.tiles = 0;
     r.r0 = r.r1 = r.r2 = f4{0.f, 0.f, 0.f, 0.f};
     r.rect = u2{0u, 0u};
+    r.ref_rect = u2{0u, 0u};
+    r.ref_tiles = 0;
     if (o.vis == VIS_OK) {
         float rgb[3];
         if (fused) {
@@ -107,11 +114,13 @@ GS_HD RecOut project_finish(const GaussIn& in, const Proj& o, bool fused, Coef c
         } else {
             rgb[0] = in.col[0]; rgb[1] = in.col[1]; rgb[2] = in.col[2];
         }
-        r.tiles = (uint32_t)((o.tx1 - o.tx0 + 1) * (o.ty1 - o.ty0 + 1));
+        r.ref_tiles = (uint32_t)((o.tx1 - o.tx0 + 1) * (o.ty1 - o.ty0 + 1));
+        r.ref_rect = u2{(uint32_t)o.tx0 | ((uint32_t)o.ty0 << 16), (uint32_t)o.tx1 | ((uint32_t)o.ty1 << 16)};
+        if (o.bx1 >= o.bx0 && o.by1 >= o.by0) r.tiles = (uint32_t)((o.bx1 - o.bx0 + 1) * (o.by1 - o.by0 + 1));
         r.r0 = f4{o.u, o.v, o.A11, o.A12};
         r.r1 = f4{o.A22, o.opacity, o.ex, o.ey};
         r.r2 = f4{rgb[0], rgb[1], rgb[2], o.z};
-        r.rect = u2{(uint32_t)o.tx0 | ((uint32_t)o.ty0 << 16), (uint32_t)o.tx1 | ((uint32_t)o.ty1 << 16)};
+        if (r.tiles) r.rect = u2{(uint32_t)o.bx0 | ((uint32_t)o.by0 << 16), (uint32_t)o.bx1 | ((uint32_t)o.by1 << 16)};
     }
     return r;
 }
@@ -180,8 +189,10 @@ GS_HD int project_one(int64_t i, const gsplat_gaussians& g, bool fused, Coef coe
     if (r.vis == VIS_OK) {
         out.rec[i].r0 = r.r0; out.rec[i].r1 = r.r1; out.rec[i].r2 = r.r2;
         out.rect[i] = r.rect; out.depth[i] = r.r2.w;
+        if (out.ref_rect) out.ref_rect[i] = r.ref_rect;
     }
     out.tiles[i] = r.tiles;
+    if (out.ref_tiles) out.ref_tiles[i] = r.ref_tiles;
     return r.vis;
 }
 

@@ -221,7 +221,8 @@ struct Proj {
     float A11, A12, A22;          // conic
     float ex, ey;                 // half-extents of {q <= chi_square_clip} along u and v (+inf if the conic is not PD)
     float opacity;
-    int tx0, ty0, tx1, ty1;       // inclusive tile rectangle
+    int tx0, ty0, tx1, ty1;       // inclusive tile rectangle of the reference (F10/F11: square 2.5-sigma AABB, T x T tiles)
+    int bx0, by0, bx1, by1;       // inclusive rectangle actually binned: tight box, T x T/2 half tiles (empty: bx1 < bx0)
     int vis;                      // VIS_*
 };
 
@@ -229,6 +230,7 @@ GS_HD void project_gaussian(const float p[3], const float S[6], float o_raw, con
                             ProjMid& m) {
     o.vis = VIS_CULLED;
     o.tx0 = o.ty0 = 0; o.tx1 = o.ty1 = -1;
+    o.bx0 = o.by0 = 0; o.bx1 = o.by1 = -1;
     // F4 opacity prefilter
     m.sg = sigmoidf_(o_raw);
     o.opacity = clampf_(m.sg, 0.f, 0.999f);
@@ -324,6 +326,20 @@ GS_HD void project_gaussian(const float p[3], const float S[6], float o_raw, con
     o.ty0 = (int)clampf_(vmin, 0.f, hm) / vk.tile;
     o.ty1 = (int)clampf_(vmax, 0.f, hm) / vk.tile;
     o.vis = VIS_OK;
+    // What is binned: the tight box (the only pixels with q <= chi, i.e. alpha != 0) cut to the reference's AABB and
+    // to the image, in lists of one HALF tile (T wide, T/2 tall = one wave64 with two pixels per lane).  The image does
+    // not depend on the binning: a Gaussian missing from a list has alpha = 0 on all of its pixels.
+    {
+        const float lo_u = fmaxf(floorf(o.u - o.ex), umin), hi_u = fminf(floorf(o.u + o.ex), umax);
+        const float lo_v = fmaxf(floorf(o.v - o.ey), vmin), hi_v = fminf(floorf(o.v + o.ey), vmax);
+        if (hi_u >= 0.f && lo_u <= wm && hi_v >= 0.f && lo_v <= hm && lo_u <= hi_u && lo_v <= hi_v) {
+            const int half = vk.tile / 2;
+            o.bx0 = (int)clampf_(lo_u, 0.f, wm) / vk.tile;
+            o.bx1 = (int)clampf_(hi_u, 0.f, wm) / vk.tile;
+            o.by0 = (int)clampf_(lo_v, 0.f, hm) / half;
+            o.by1 = (int)clampf_(hi_v, 0.f, hm) / half;
+        }
+    }
 }
 
 // B2.  Inputs: gradients w.r.t. (u, v, A11, A12, A22, opacity) of a VISIBLE Gaussian (its ProjMid recomputed by

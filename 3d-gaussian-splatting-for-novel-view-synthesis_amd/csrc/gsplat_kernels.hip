@@ -18,10 +18,8 @@
 #include <cstring>
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "gs_body.h"
 
@@ -56,27 +54,34 @@ inline int64_t up(int64_t x) { return (x + ALIGN - 1) / ALIGN * ALIGN; }
 // ---- layout of the caller-owned buffers (private to the library) ---------------------------------
 struct DevCounts {           // device-side counters; copied into gsplat_counts
     int32_t n_survivors, n_visible;
-    int64_t n_pairs;
+    int64_t n_pairs;         // the reference's (tile, Gaussian) pairs (F11)
     int32_t max_tiles, reserved;
+    int64_t n_binned;        // (half-tile list, Gaussian) pairs actually binned
 };
 static_assert(sizeof(DevCounts) == sizeof(gsplat_counts), "counts layout");
 
 constexpr int COUNT_SHARDS = 256;     // per-wave counters are spread over 256 cache lines (same-address atomics serialise)
-struct alignas(64) CountShard { int32_t survivors, visible, max_tiles, pad[13]; };
+struct alignas(64) CountShard { int32_t survivors, visible, max_tiles; uint32_t ref_pairs, bin_pairs; int32_t pad[11]; };
 
+// A "list" is the depth-ordered set of Gaussians of one HALF tile (16 x 8 pixels): the unit one wave64 rasterises.
 struct ProjectState {
     Camera* cam;
     DevCounts* counts;
     CountShard* shards;
     Rec64* rec;
-    u2* rect;
+    u2* rect;                // per Gaussian: inclusive rectangle of lists
     float* depth;
-    uint32_t* tiles;
-    uint32_t* offsets;       // inclusive prefix sum of tiles
+    uint32_t* tiles;         // per Gaussian: number of lists (0 = contributes nowhere)
+    uint32_t* wave_off;      // [ceil(n / 64)] pairs of each 64-Gaussian block, then (scan_kernel) their exclusive prefix
+    uint2* ranges;           // [lists] start, end in the pair arrays
+    uint32_t* order;         // [lists] launch order: longest list first
+    uint32_t* class_bounds;  // [8] boundaries of the sort size classes inside `order`
     int64_t bytes;
 };
 
-ProjectState carve_project(void* base, int64_t n) {
+inline int64_t n_lists(const gsplat_view* v) { return (int64_t)((v->W + 15) / 16) * ((v->H + 7) / 8); }
+
+ProjectState carve_project(void* base, int64_t n, int64_t nl) {
     ProjectState s;
     char* p = (char*)base;
     int64_t o = 0;
@@ -87,38 +92,19 @@ ProjectState carve_project(void* base, int64_t n) {
     s.rect = (u2*)(p + o); o += up(n * 8);
     s.depth = (float*)(p + o); o += up(n * 4);
     s.tiles = (uint32_t*)(p + o); o += up(n * 4);
-    s.offsets = (uint32_t*)(p + o); o += up(n * 4);
+    s.wave_off = (uint32_t*)(p + o); o += up((n + 63) / 64 * 4);
+    s.ranges = (uint2*)(p + o); o += up(nl * 8);
+    s.order = (uint32_t*)(p + o); o += up(nl * 4);
+    s.class_bounds = (uint32_t*)(p + o); o += up(8 * 4);
     s.bytes = o;
     return s;
 }
 
-struct BinState {
-    uint32_t* sorted_ids;    // [P] Gaussian ids in (tile, depth, id) order
-    uint2* ranges;           // [tiles] start, end
-    uint32_t* order_fwd;     // [tiles] launch order of the forward raster (longest list first)
-    uint32_t* order_bwd;     // [tiles] launch order of the backward raster (most visited first)
-    uint32_t* visited;       // [2 * tiles] Gaussians the forward visited per half tile
-    int64_t bytes;
-};
-
-BinState carve_bin(void* base, int64_t n_pairs, int64_t n_tiles) {
-    BinState s;
-    char* p = (char*)base;
-    int64_t o = 0;
-    s.sorted_ids = (uint32_t*)(p + o); o += up((n_pairs > 0 ? n_pairs : 1) * 4);
-    s.ranges = (uint2*)(p + o); o += up(n_tiles * 8);
-    s.order_fwd = (uint32_t*)(p + o); o += up(n_tiles * 4);
-    s.order_bwd = (uint32_t*)(p + o); o += up(n_tiles * 4);
-    s.visited = (uint32_t*)(p + o); o += up(n_tiles * 8);
-    s.bytes = o;
-    return s;
-}
-
-// Binning scratch.  Pairs are radix-sorted by tile id only (ceil(log2 tiles) key bits: 2 onesweep passes at 1080p) with a
-// 64-bit payload (depth bits << 32 | Gaussian id); the depth order inside every tile is then produced by a per-tile
-// bitonic sort in LDS (tile_sort_kernel).  Sorting 64-bit (tile, depth) keys globally took 6 passes.
+// Binning scratch.  Pairs are radix-sorted by list id only (ceil(log2 lists) key bits: 2 onesweep passes) with a 64-bit
+// payload (depth bits << 32 | Gaussian id); the depth order inside every list is then produced by a per-list sort in LDS
+// (list_sort_kernel).  Sorting 64-bit (list, depth) keys globally took 6 passes.
 struct BinScratch {
-    uint32_t *keys_in, *keys_out;     // [P] tile id
+    uint32_t *keys_in, *keys_out;     // [P] list id
     uint64_t *vals_in, *vals_out;     // [P] depth bits << 32 | id
     void* temp;
     size_t temp_bytes;
@@ -145,13 +131,6 @@ BinScratch carve_bin_scratch(void* base, int64_t n_pairs) {
     s.temp = (void*)(p + o); o += up((int64_t)s.temp_bytes);
     s.bytes = o;
     return s;
-}
-
-size_t scan_temp_bytes(int64_t n) {
-    size_t bytes = 0;
-    (void)rocprim::inclusive_scan(nullptr, bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)(n > 0 ? n : 1),
-                            rocprim::plus<uint32_t>(), (hipStream_t)0);
-    return bytes;
 }
 
 int check_view(const gsplat_view* v) {
@@ -232,15 +211,21 @@ __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t n) {
 }
 
 // ---- K0 ------------------------------------------------------------------------------------------
-__global__ void camera_kernel(const float* __restrict__ c2w, Camera* cam, DevCounts* counts, CountShard* shards) {
-    if (threadIdx.x < COUNT_SHARDS) { shards[threadIdx.x].survivors = 0; shards[threadIdx.x].visible = 0; shards[threadIdx.x].max_tiles = 0; }
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+__global__ __launch_bounds__(256) void camera_kernel(const float* __restrict__ c2w, Camera* cam, DevCounts* counts, CountShard* shards) {
+    if (threadIdx.x < COUNT_SHARDS) {
+        CountShard z;
+        z.survivors = 0; z.visible = 0; z.max_tiles = 0; z.ref_pairs = 0u; z.bin_pairs = 0u;
+        for (int k = 0; k < 11; ++k) z.pad[k] = 0;
+        shards[threadIdx.x] = z;
+    }
+    if (threadIdx.x == 0) {
         float m[16];
-        for (int i = 0; i < 16; ++i) m[i] = c2w[i];
+        for (int k = 0; k < 16; ++k) m[k] = c2w[k];
         Camera c;
         build_camera(m, c);
         *cam = c;
         counts->n_survivors = 0; counts->n_visible = 0; counts->n_pairs = 0; counts->max_tiles = 0; counts->reserved = 0;
+        counts->n_binned = 0;
     }
 }
 
@@ -330,9 +315,33 @@ __device__ __forceinline__ void stage_geometry(ProjectLds& s, const gsplat_gauss
     }
 }
 
+// Calls f(list, ordinal, a, b) for every half-tile list of a Gaussian's rectangle (row-major ordinal 0 .. nt - 1; a, b =
+// the owning lane's values).  Small rectangles: each lane walks its own; rectangles of more than 32 lists (huge
+// Gaussians: up to 32 x 64 lists) are walked by the whole wave, one after the other.  Call with all 64 lanes active.
+template <class F>
+__device__ __forceinline__ void for_each_list(u2 rect, uint32_t nt, int tiles_x, int lane, uint64_t a, uint32_t b, F f) {
+    const int x0 = rect.x & 0xFFFF, y0 = rect.x >> 16, x1 = rect.y & 0xFFFF, y1 = rect.y >> 16;
+    const bool big = nt > 32u;
+    if (nt && !big) {
+        uint32_t k = 0;
+        for (int y = y0; y <= y1; ++y)
+            for (int x = x0; x <= x1; ++x) f((uint32_t)(y * tiles_x + x), k++, a, b);
+    }
+    unsigned long long m = __ballot(big);
+    while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int sx0 = __shfl(x0, src), sy0 = __shfl(y0, src), sx1 = __shfl(x1, src);
+        const int cnt = (int)__shfl((int)nt, src), w = sx1 - sx0 + 1;
+        const uint64_t sa = ((uint64_t)(uint32_t)__shfl((int)(a >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)a, src);
+        const uint32_t sb = (uint32_t)__shfl((int)b, src);
+        for (int k = lane; k < cnt; k += 64) f((uint32_t)((sy0 + k / w) * tiles_x + sx0 + k % w), (uint32_t)k, sa, sb);
+    }
+}
+
 template <bool FUSED>
 __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const Camera* __restrict__ camp, ViewK vk, Records out,
-                                                     CountShard* shards) {
+                                                     CountShard* shards, uint32_t* __restrict__ wave_pairs) {
     __shared__ ProjectLds s;
     __shared__ float s_dc[FUSED ? 64 * 3 : 4];
     __shared__ float s_rest[FUSED ? 64 * 45 : 4];
@@ -349,7 +358,7 @@ __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const C
         o = project_geometry(in, FUSED, cam, vk);
     }
     RecOut r;
-    r.vis = o.vis; r.tiles = 0;
+    r.vis = o.vis; r.tiles = 0; r.ref_tiles = 0; r.rect = u2{0u, 0u}; r.ref_rect = u2{0u, 0u};
     if (FUSED) {
         if (__any(o.vis == VIS_OK)) {                        // wave-uniform: skip 192 B / Gaussian when all are culled
             stage_rows<3>(s_dc, g.f_dc, row0, g.n, lane);
@@ -372,57 +381,117 @@ __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const C
     }
     const unsigned long long surv = __ballot(o.vis != VIS_CULLED);
     const unsigned long long seen = __ballot(o.vis == VIS_OK);
-    uint32_t mx = r.tiles;
-    for (int sft = 32; sft > 0; sft >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, sft));
+    uint32_t mx = r.tiles, refp = r.ref_tiles, binp = r.tiles;
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, sft));
+        refp += (uint32_t)__shfl_xor((int)refp, sft);
+        binp += (uint32_t)__shfl_xor((int)binp, sft);
+    }
     if (lane == 0) {
         CountShard* sh = shards + (blockIdx.x % COUNT_SHARDS);
         if (surv) atomicAdd(&sh->survivors, (int)__popcll(surv));
         if (seen) atomicAdd(&sh->visible, (int)__popcll(seen));
         if (mx) atomicMax(&sh->max_tiles, (int)mx);
+        if (refp) atomicAdd(&sh->ref_pairs, refp);
+        if (binp) atomicAdd(&sh->bin_pairs, binp);
+        wave_pairs[blockIdx.x] = binp;            // scanned by scan_kernel -> where this block's pairs start
     }
 }
 
-__global__ __launch_bounds__(COUNT_SHARDS) void finish_counts_kernel(const uint32_t* __restrict__ offsets, int64_t n,
-                                                                     const CountShard* __restrict__ shards, DevCounts* counts) {
-    __shared__ int part[3][COUNT_SHARDS / 64];
-    int a = shards[threadIdx.x].survivors, b = shards[threadIdx.x].visible, c = shards[threadIdx.x].max_tiles;
-    for (int sft = 32; sft > 0; sft >>= 1) { a += __shfl_xor(a, sft); b += __shfl_xor(b, sft); c = max(c, __shfl_xor(c, sft)); }
-    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = a; part[1][threadIdx.x >> 6] = b; part[2][threadIdx.x >> 6] = c; }
+// ---- K2: scan --------------------------------------------------------------------------------------
+// One workgroup: exclusive prefix over the per-block (64 Gaussians) pair counts, in place, and the totals of the sharded
+// counters.  Replaces a device-wide scan over all Gaussians (three library kernels) and the counter reduction.
+__global__ __launch_bounds__(1024) void scan_kernel(int nw, uint32_t* __restrict__ wave_off, const CountShard* __restrict__ shards,
+                                                    DevCounts* counts) {
+    constexpr int K = 16;                                    // entries per thread and round, held in registers
+    __shared__ uint32_t wsum[16];
+    __shared__ long long tot[5];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 5) tot[tid] = 0;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int sa = 0, sb = 0, sc = 0;
-        for (int k = 0; k < COUNT_SHARDS / 64; ++k) { sa += part[0][k]; sb += part[1][k]; sc = max(sc, part[2][k]); }
-        counts->n_survivors = sa; counts->n_visible = sb; counts->max_tiles = sc;
-        counts->n_pairs = n > 0 ? (int64_t)offsets[n - 1] : 0;
+    uint32_t carry = 0u;
+    for (int base = 0; base < nw; base += 1024 * K) {
+        const int first = base + tid * K;
+        uint32_t c[K], run = 0u;
+#pragma unroll
+        for (int k = 0; k < K; ++k) c[k] = first + k < nw ? wave_off[first + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < K; ++k) run += c[k];
+        uint32_t incl = run;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up_ = (uint32_t)__shfl_up((int)incl, d);
+            if (lane >= d) incl += up_;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0u, total = 0u;
+        for (int k = 0; k < 16; ++k) { const uint32_t v = wsum[k]; if (k < wave) woff += v; total += v; }
+        uint32_t st = carry + woff + incl - run;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (first + k < nw) wave_off[first + k] = st;
+            st += c[k];
+        }
+        carry += total;
+        __syncthreads();
+    }
+    if (tid < COUNT_SHARDS) {           // totals of the sharded counters (COUNT_SHARDS <= 1024): wave sums, then 4 x 5 LDS atomics
+        const CountShard sh = shards[tid];
+        unsigned long long v[4] = {(unsigned long long)sh.survivors, (unsigned long long)sh.visible, (unsigned long long)sh.ref_pairs,
+                                   (unsigned long long)sh.bin_pairs};
+        uint32_t mxt = (uint32_t)sh.max_tiles;
+        for (int sft = 32; sft > 0; sft >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += (unsigned long long)__shfl_xor((long long)v[k], sft);
+            mxt = max(mxt, (uint32_t)__shfl_xor((int)mxt, sft));
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) atomicAdd((unsigned long long*)&tot[k], v[k]);
+            atomicMax((unsigned long long*)&tot[4], (unsigned long long)mxt);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        counts->n_survivors = (int32_t)tot[0]; counts->n_visible = (int32_t)tot[1]; counts->n_pairs = tot[2];
+        counts->n_binned = tot[3]; counts->max_tiles = (int32_t)tot[4];
     }
 }
 
-// ---- K3 ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void emit_pairs_kernel(int64_t n, const float* __restrict__ depth, const u2* __restrict__ rect,
-                                                         const uint32_t* __restrict__ tiles, const uint32_t* __restrict__ offsets,
-                                                         int tiles_x, int64_t n_pairs, uint32_t* __restrict__ keys,
-                                                         uint64_t* __restrict__ vals) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t nt = tiles[i];
-    if (nt == 0) return;
-    const u2 r = rect[i];
-    const int tx0 = r.x & 0xFFFF, ty0 = r.x >> 16, tx1 = r.y & 0xFFFF, ty1 = r.y >> 16;
-    // z > 0: the float's bit pattern orders like its value; equal depths fall back to the Gaussian index (low word)
-    const uint64_t payload = ((uint64_t)f2u(depth[i]) << 32) | (uint64_t)(uint32_t)i;
-    int64_t o = (int64_t)offsets[i] - nt;
-    for (int ty = ty0; ty <= ty1; ++ty)
-        for (int tx = tx0; tx <= tx1; ++tx) {
-            if (o < n_pairs) {                     // defensive: never write past the caller's buffer
-                keys[o] = (uint32_t)(ty * tiles_x + tx);
-                vals[o] = payload;
-            }
-            ++o;
+// ---- K3: emit --------------------------------------------------------------------------------------
+// F11: key = list id (u32), payload = float_bits(z) << 32 | Gaussian index (u64).  z > 0, so the bit pattern orders
+// like the value; equal depths fall back to the index.  Same 64-Gaussian blocks as project_kernel.
+__global__ __launch_bounds__(64) void emit_pairs_kernel(int64_t n, const float* __restrict__ depth, const u2* __restrict__ rect,
+                                                        const uint32_t* __restrict__ tiles, const uint32_t* __restrict__ wave_off,
+                                                        int tiles_x, uint32_t n_binned, uint32_t* __restrict__ keys,
+                                                        uint64_t* __restrict__ vals) {
+    const int lane = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    const uint32_t nt = i < n ? tiles[i] : 0u;
+    if (!__any(nt != 0u)) return;
+    uint32_t incl = nt;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up_ = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += up_;
+    }
+    const uint32_t first = wave_off[blockIdx.x] + incl - nt;
+    u2 r = u2{0u, 0u};
+    uint64_t payload = 0ull;
+    if (nt) {
+        r = rect[i];
+        payload = ((uint64_t)f2u(depth[i]) << 32) | (uint64_t)(uint32_t)i;
+    }
+    for_each_list(r, nt, tiles_x, lane, payload, first, [&](uint32_t l, uint32_t k, uint64_t pl, uint32_t at) {
+        const uint32_t pos = at + k;
+        if (pos < n_binned) {                               // defensive: never write past the caller's buffer
+            keys[pos] = l;
+            vals[pos] = pl;
         }
+    });
 }
 
-// ---- K5 ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t n_pairs, const uint32_t* __restrict__ keys, uint2* ranges) {
+// ---- K5: list ranges and plan ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void list_ranges_kernel(int64_t n_pairs, const uint32_t* __restrict__ keys, uint2* ranges) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_pairs) return;
     const uint32_t t = keys[i];
@@ -430,16 +499,68 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(int64_t n_pairs, const
     if (i == n_pairs - 1 || keys[i + 1] != t) ranges[t].y = (uint32_t)(i + 1);
 }
 
-// ---- K4b: per-tile depth sort ----------------------------------------------------------------------
-// One workgroup per tile sorts the tile's (depth bits << 32 | id) payloads ascending with a bitonic network and writes
-// the ids.  Lists of up to TILE_SORT_LDS entries are sorted in LDS; longer ones in place in global memory by the same
-// workgroup (slow path, exact).  Keys are unique (the id is part of the key), so the result is deterministic.
-// Two size classes share the code: lists of up to 512 entries (almost all tiles) use 128 threads and 4 KB of LDS, so
-// 16 workgroups fit a CU; longer lists use 256 threads and 32 KB.  Each launch covers all tiles and a workgroup
-// returns at once when its tile belongs to the other class.
-constexpr int TILE_SORT_LDS = 4096;            // largest list sorted in LDS (32 KB of 64-bit keys)
-constexpr int TILE_SORT_SMALL = 512;
+// Longest-processing-time-first launch order of the lists (1/8-octave buckets of the list length: the raster kernels
+// are tail-bound, a few dense lists take 5x the mean, so they must start first), and the boundaries of the sort size
+// classes inside that order.
+__device__ __forceinline__ uint32_t work_bucket(uint32_t w) {
+    if (w < 8u) return w;
+    const uint32_t e = 31u - (uint32_t)__clz((int)w);
+    return (e - 2u) * 8u + ((w >> (e - 3u)) & 7u);          // <= 239; 256 -> 48, 1024 -> 64, 4096 -> 80
+}
+constexpr int SORT_CLASSES = 4;                               // list length >= 4096 | >= 1024 | >= 256 | >= 1
+__device__ __forceinline__ uint32_t class_first_bucket(int c) { return c == 0 ? 80u : (c == 1 ? 64u : (c == 2 ? 48u : 1u)); }
 
+// Counting sort of the lists by work bucket, descending.  Same-address LDS atomics serialise and neighbouring lists
+// often share a bucket, so every bucket has 16 sub-counters selected by the lane (flat index = (255 - bucket) * 16 + sub:
+// ascending flat index = descending bucket).
+__global__ __launch_bounds__(1024) void plan_kernel(int nl, const uint2* __restrict__ ranges, uint32_t* __restrict__ order,
+                                                    uint32_t* __restrict__ class_bounds) {
+    constexpr int SUB = 16, NF = 256 * SUB;
+    __shared__ uint32_t cnt[NF], wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = tid & (SUB - 1);
+    for (int f = tid; f < NF; f += 1024) cnt[f] = 0u;
+    __syncthreads();
+    for (int i = tid; i < nl; i += 1024) {
+        const uint2 rg = ranges[i];
+        atomicAdd(&cnt[(255u - work_bucket(rg.y - rg.x)) * SUB + sub], 1u);
+    }
+    __syncthreads();
+    // exclusive prefix over the NF counters: thread t owns 4 consecutive ones
+    uint32_t c[4], run = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { c[k] = cnt[tid * 4 + k]; run += c[k]; }
+    uint32_t incl = run;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up_ = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += up_;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t st = incl - run;
+    for (int k = 0; k < wave; ++k) st += wsum[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { cnt[tid * 4 + k] = st; st += c[k]; }
+    __syncthreads();
+    // lists in buckets >= first bucket of a class = prefix at the first sub-counter of the bucket below it
+    if (tid < SORT_CLASSES) class_bounds[tid] = cnt[(256u - class_first_bucket(tid)) * SUB];
+    __syncthreads();
+    for (int i = tid; i < nl; i += 1024) {
+        const uint2 rg = ranges[i];
+        order[atomicAdd(&cnt[(255u - work_bucket(rg.y - rg.x)) * SUB + sub], 1u)] = (uint32_t)i;
+    }
+}
+
+// ---- K4: per-list depth sort ------------------------------------------------------------------------
+// One workgroup per list sorts the list's payloads ascending = (depth, Gaussian index) order and writes the ids.
+// Keys are unique, so the result does not depend on the arrival order of the scatter.
+//
+// list_sort_kernel (lists shorter than T * E): one-pass distribution sort in LDS.  The depth bits (monotone in z) are
+// mapped to B >= 2 n buckets by subtracting the list minimum and shifting; count (LDS atomics) -> exclusive scan ->
+// scatter gives bucket order; inside a bucket (expected occupancy <= 0.5) every element counts the smaller keys to find
+// its rank.  ~8 barriers instead of the ~70 compare-exchange rounds of a bitonic network.  A list whose depths are so
+// clustered that a bucket holds more than DENSE_BUCKET entries takes the bitonic network instead (exact, slower).
+// huge_sort_kernel (lists of 4096 and more): bitonic network in place in global memory.
+//
 // Direction-free bitonic network: every merge of size k starts with a mirror step (i <-> block_end - i), followed by
 // the half-cleaner steps j = k/4 .. 1; every compare-exchange puts the smaller key at the lower index.  With virtual
 // +inf padding above n no real element is ever exchanged with the padding, so the network also runs in place.
@@ -465,88 +586,147 @@ __device__ __forceinline__ void bitonic_network(uint32_t n, uint32_t m, int tid,
     }
 }
 
-template <int THREADS, int CAP, bool LARGE>
-__global__ __launch_bounds__(THREADS) void tile_sort_kernel(const uint2* __restrict__ ranges, uint64_t* __restrict__ vals,
-                                                            uint32_t* __restrict__ sorted_ids) {
+constexpr uint32_t DENSE_BUCKET = 48;
+
+template <int T, int E, int LOG2B>
+__global__ __launch_bounds__(T) void list_sort_kernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ class_bounds,
+                                                      int cls, const uint2* __restrict__ ranges, const uint64_t* __restrict__ vals,
+                                                      uint32_t* __restrict__ sorted_ids) {
+    constexpr int CAP = T * E, B = 1 << LOG2B, CPT = B / T;       // CPT counters per thread in the scan
+    static_assert((CPT & (CPT - 1)) == 0 && CPT >= 2, "B / T must be a power of two");
+    constexpr int LOG2CPT = __builtin_ctz(CPT);
     __shared__ uint64_t sk[CAP];
-    const uint2 rg = ranges[blockIdx.x];
-    const uint32_t n = rg.y - rg.x;
-    if (n == 0) return;
-    if (LARGE ? (n <= (uint32_t)TILE_SORT_SMALL) : (n > (uint32_t)TILE_SORT_SMALL)) return;     // the other launch's tile
+    __shared__ uint32_t cnt[B + T];                               // padded: counter c lives at c + c / CPT (conflict-free scan)
+    __shared__ uint32_t red[4 + T / 64];
+    const uint32_t lo = class_bounds[cls - 1], hi = class_bounds[cls];
+    if (lo + blockIdx.x >= hi) return;
     const int tid = threadIdx.x;
-    uint64_t* g = vals + rg.x;
+    const uint2 rg = ranges[order[lo + blockIdx.x]];
+    const uint32_t n = rg.y - rg.x;                               // 1 <= n < CAP by the class bounds
+    const uint64_t* __restrict__ g = vals + rg.x;
     uint32_t* __restrict__ out = sorted_ids + rg.x;
-    uint32_t m = 2;
-    while (m < n) m <<= 1;                     // padded size (power of two); entries >= n are virtual +inf
-    if (n <= (uint32_t)CAP) {
-        for (uint32_t i = tid; i < n; i += THREADS) sk[i] = g[i];
+#define PADC(c) ((c) + ((c) >> LOG2CPT))
+    uint64_t key[E];
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint32_t i = (uint32_t)(e * T + tid);
+        key[e] = i < n ? g[i] : ~0ull;
+        if (i < n) { mn = min(mn, (uint32_t)(key[e] >> 32)); mx = max(mx, (uint32_t)(key[e] >> 32)); }
+    }
+    for (int c = tid; c < B + T; c += T) cnt[c] = 0u;
+    if (tid == 0) { red[0] = 0xFFFFFFFFu; red[1] = 0u; red[2] = 0u; }
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        mn = min(mn, (uint32_t)__shfl_xor((int)mn, sft));
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, sft));
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) { atomicMin(&red[0], mn); atomicMax(&red[1], mx); }
+    __syncthreads();
+    mn = red[0];
+    const uint32_t range = red[1] - mn;
+    const int bl = range ? 32 - __clz((int)range) : 0;
+    const int shift = bl > LOG2B ? bl - LOG2B : 0;              // (range >> shift) < B
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if ((uint32_t)(e * T + tid) < n) {
+            const uint32_t b = ((uint32_t)(key[e] >> 32) - mn) >> shift;
+            atomicAdd(&cnt[PADC(b)], 1u);
+        }
+    __syncthreads();
+    // exclusive scan of the B counters: thread t owns counters [t CPT, (t + 1) CPT)
+    uint32_t loc[CPT], run = 0u, big = 0u;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const uint32_t v = cnt[tid * (CPT + 1) + k];
+        loc[k] = run;
+        run += v;
+        big = max(big, v);
+    }
+    uint32_t incl = run;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up_ = (uint32_t)__shfl_up((int)incl, d);
+        if ((tid & 63) >= d) incl += up_;
+    }
+    for (int sft = 32; sft > 0; sft >>= 1) big = max(big, (uint32_t)__shfl_xor((int)big, sft));
+    if ((tid & 63) == 63) red[4 + (tid >> 6)] = incl;
+    if ((tid & 63) == 0) atomicMax(&red[2], big);
+    __syncthreads();
+    uint32_t toff = incl - run;
+    for (int k = 0; k < (tid >> 6); ++k) toff += red[4 + k];
+    if (red[2] > DENSE_BUCKET) {                                  // clustered depths: exact fallback (uniform branch)
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if ((uint32_t)(e * T + tid) < n) sk[e * T + tid] = key[e];
+        uint32_t m = 2;
+        while (m < n) m <<= 1;
         __syncthreads();
-        bitonic_network<THREADS>(n, m, tid, [&](uint32_t i, uint32_t l) {
+        bitonic_network<T>(n, m, tid, [&](uint32_t i, uint32_t l) {
             const uint64_t a = sk[i], b = sk[l];
             if (a > b) { sk[i] = b; sk[l] = a; }
         });
-        for (uint32_t i = tid; i < n; i += THREADS) out[i] = (uint32_t)sk[i];
-    } else {
-        bitonic_network<THREADS>(n, m, tid, [&](uint32_t i, uint32_t l) {
-            const uint64_t a = g[i], b = g[l];
-            if (a > b) { g[i] = b; g[l] = a; }
-        });
-        for (uint32_t i = tid; i < n; i += THREADS) out[i] = (uint32_t)g[i];
+        for (uint32_t i = tid; i < n; i += T) out[i] = (uint32_t)sk[i];
+        return;
     }
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) cnt[tid * (CPT + 1) + k] = toff + loc[k];
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+        if ((uint32_t)(e * T + tid) < n) {
+            const uint32_t b = ((uint32_t)(key[e] >> 32) - mn) >> shift;
+            sk[atomicAdd(&cnt[PADC(b)], 1u)] = key[e];
+        }
+    __syncthreads();
+    // cnt[b] is now the END of bucket b; rank inside the bucket by counting smaller keys
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint32_t p = (uint32_t)(e * T + tid);
+        if (p < n) {
+            const uint64_t k = sk[p];
+            const uint32_t b = ((uint32_t)(k >> 32) - mn) >> shift;
+            const uint32_t s = b ? cnt[PADC(b - 1u)] : 0u, en = cnt[PADC(b)];
+            uint32_t r = s;
+            for (uint32_t q = s; q < en; ++q) r += sk[q] < k ? 1u : 0u;
+            out[r] = (uint32_t)k;
+        }
+    }
+#undef PADC
 }
 
-// ---- K5b: launch order ------------------------------------------------------------------------------
-// Longest-processing-time-first order of the tiles (descending work, 1/8-octave buckets).  The raster kernels are
-// tail-bound: a few dense tiles take 5x the mean, so they must start first (and get issue priority, see s_setprio).
-// work(t) = list length (forward) or the number of Gaussians the forward actually visited in the tile (backward).
-__device__ __forceinline__ uint32_t work_bucket(uint32_t w) {
-    if (w < 8u) return w;
-    const uint32_t e = 31u - (uint32_t)__clz((int)w);
-    return (e - 2u) * 8u + ((w >> (e - 3u)) & 7u);          // <= 239
-}
-
-__global__ __launch_bounds__(1024) void order_tiles_kernel(int n_tiles, const uint2* __restrict__ ranges,
-                                                           const uint32_t* __restrict__ visited, uint32_t* __restrict__ order) {
-    __shared__ uint32_t hist[256], cursor[256];
+__global__ __launch_bounds__(256) void huge_sort_kernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ class_bounds,
+                                                        const uint2* __restrict__ ranges, uint64_t* __restrict__ vals,
+                                                        uint32_t* __restrict__ sorted_ids) {
+    if (blockIdx.x >= class_bounds[0]) return;
+    const uint2 rg = ranges[order[blockIdx.x]];
+    const uint32_t n = rg.y - rg.x;
     const int tid = threadIdx.x;
-    if (tid < 256) hist[tid] = 0;
-    __syncthreads();
-    for (int t = tid; t < n_tiles; t += 1024) {
-        const uint32_t w = visited ? visited[2 * t] + visited[2 * t + 1] : ranges[t].y - ranges[t].x;
-        atomicAdd(&hist[work_bucket(w)], 1u);
-    }
-    __syncthreads();
-    if (tid < 256) {
-        uint32_t above = 0;
-        for (int k = 255; k > tid; --k) above += hist[k];
-        cursor[tid] = above;
-    }
-    __syncthreads();
-    for (int t = tid; t < n_tiles; t += 1024) {
-        const uint32_t w = visited ? visited[2 * t] + visited[2 * t + 1] : ranges[t].y - ranges[t].x;
-        order[atomicAdd(&cursor[work_bucket(w)], 1u)] = (uint32_t)t;
-    }
+    uint64_t* g = vals + rg.x;
+    uint32_t m = 2;
+    while (m < n) m <<= 1;
+    bitonic_network<256>(n, m, tid, [&](uint32_t i, uint32_t l) {
+        const uint64_t a = g[i], b = g[l];
+        if (a > b) { g[i] = b; g[l] = a; }
+    });
+    for (uint32_t i = tid; i < n; i += 256) sorted_ids[rg.x + i] = (uint32_t)g[i];
 }
 
 // ---- K6 / K7: rasterizer -----------------------------------------------------------------------------
-// One wave64 per HALF tile (16 x 8 pixels): lane l owns column (l & 15) and rows (l >> 4) and (l >> 4) + 4 of the
-// half, so the two pixels of a lane form a float2 and the arithmetic runs on packed fp32 (v_pk_fma_f32 ...).
+// One wave64 per list = per HALF tile (16 x 8 pixels): lane l owns column (l & 15) and rows (l >> 4) and (l >> 4) + 4 of
+// the half, so the two pixels of a lane form a float2 and the arithmetic runs on packed fp32 (v_pk_fma_f32 ...).
 //
-// Staging = binning at wave granularity: the wave walks its tile's depth-sorted list 64 entries at a time; lane l
-// fetches entry l's record and tests the Gaussian's tight box {q <= chi} (ex, ey of the record) against the wave's
-// 16 x 8 pixel rectangle.  __ballot + mbcnt give every survivor its slot, in list order, and the survivors are
-// compacted into LDS.  The wave-wide inner loop then only visits Gaussians that can touch its pixels; a rejected
-// Gaussian costs one lane a few instructions instead of costing the whole wave an inner-loop iteration.  Skipping is
-// exact: a Gaussian whose box misses the rectangle has q > chi at every pixel there, i.e. alpha = 0 and T unchanged.
-// The next chunk's records are fetched while the current chunk's survivors are composited.
+// The wave walks its depth-sorted list 64 entries at a time: lane l fetches entry l's id and its 64-byte record and
+// puts it into LDS (conic pre-scaled for exp2); the wave-wide inner loop then reads one record per Gaussian with
+// broadcast ds_read_b128.  The lists already hold only Gaussians whose tight box meets the half tile (binning does the
+// culling), so every entry is a real visit.  The next chunk's records are fetched while the current chunk is composited.
 //
-// Launch order: block b takes tile order[b >> 1], half b & 1, with `order` from order_tiles_kernel (heaviest first),
-// and the first blocks raise their wave priority so that a dense tile is not slowed down by light co-resident waves.
+// Launch order: block b takes list order[b] (longest first, from plan_kernel), and the first blocks raise their wave
+// priority so that a dense list is not slowed down by light co-resident waves.
 typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int BATCH = 64;
 
 // Diagnostics (tools/raster_stats.py): when a buffer is registered with gsplat_debug_set_stats(), every raster wave
-// writes {list length, chunks staged, survivors visited, shader cycles} for its region.  Never set in normal use.
+// writes {list length, chunks staged, entries visited, shader cycles} for its list.  Never set in normal use.
 struct WaveStats { uint32_t list_len, chunks, visited, cycles; };
 WaveStats* g_stats_fwd = nullptr;
 WaveStats* g_stats_bwd = nullptr;
@@ -555,27 +735,25 @@ int g_ablate = 0;      // diagnostics: bit 0 = no atomics, bit 1 = no wave reduc
 constexpr float QK = -0.72134752044448170368f;      // -0.5 * log2(e)
 
 struct RasterStage {
-    f4 r0[BATCH + 2];      // u, v, k A11, 2 k A12    (+2: null records that pad an odd survivor count)
+    f4 r0[BATCH + 2];      // u, v, k A11, 2 k A12    (+2: null records that pad an odd entry count)
     f4 r1[BATCH + 2];      // k A22, opacity, r, g
     float bl[BATCH + 2];   // b
     uint32_t id[BATCH + 2];
 };
 
-struct Candidate {         // one list entry held by one lane between fetch and test
+struct Candidate {         // one list entry held by one lane between fetch and staging
     f4 q0, q1, q2;
     uint32_t id;
-    bool valid;
 };
 
 __device__ __forceinline__ Candidate fetch_candidate(int lane, uint32_t base, uint32_t end, const uint32_t* __restrict__ ids,
-                                                     const Rec64* __restrict__ rec) {
+                                                     const Rec64* __restrict__ rec, uint32_t id_max) {
     Candidate c;
     const uint32_t idx = base + lane;
-    c.valid = idx < end;
     c.id = 0;
     c.q0 = c.q1 = c.q2 = f4{0.f, 0.f, 0.f, 0.f};
-    if (c.valid) {
-        c.id = ids[idx];
+    if (idx < end) {
+        c.id = min(ids[idx], id_max);                     // never gather outside the record array
         const Rec64* __restrict__ r = rec + c.id;        // one 64-byte line
         c.q0 = r->r0;
         c.q1 = r->r1;
@@ -584,30 +762,22 @@ __device__ __forceinline__ Candidate fetch_candidate(int lane, uint32_t base, ui
     return c;
 }
 
-// Cull + compact the fetched candidates into LDS, padded to an even count.  Returns the survivor count (uniform).
+// Put the fetched entries into LDS, padded to an even count with a null record.  n = entries of this chunk (uniform).
 template <bool WITH_ID>
-__device__ __forceinline__ int compact_candidates(RasterStage& s, const Candidate& c, float x0, float x1, float y0, float y1) {
-    const bool pass = c.valid && (c.q0.x + c.q1.z >= x0) && (c.q0.x - c.q1.z <= x1) && (c.q0.y + c.q1.w >= y0) &&
-                      (c.q0.y - c.q1.w <= y1);
-    const unsigned long long mask = __ballot(pass);
-    if (mask == 0ull) return 0;
-    const int n = (int)__popcll(mask);
+__device__ __forceinline__ void stage_candidates(RasterStage& s, const Candidate& c, int n, int lane) {
     __syncthreads();       // previous chunk's LDS reads are done (single-wave block: orders LDS traffic only)
-    if (pass) {
-        const int slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    if (lane < n) {
         // conic pre-scaled by k = -0.5 log2(e): the loop evaluates q' = k q and alpha = o * exp2(q') (v_exp_f32 directly)
-        s.r0[slot] = f4{c.q0.x, c.q0.y, QK * c.q0.z, (2.0f * QK) * c.q0.w};
-        s.r1[slot] = f4{QK * c.q1.x, c.q1.y, c.q2.x, c.q2.y};
-        s.bl[slot] = c.q2.z;
-        if (WITH_ID) s.id[slot] = c.id;
-    }
-    if (threadIdx.x == 0) {                                   // null record: opacity 0 -> alpha 0, T unchanged
+        s.r0[lane] = f4{c.q0.x, c.q0.y, QK * c.q0.z, (2.0f * QK) * c.q0.w};
+        s.r1[lane] = f4{QK * c.q1.x, c.q1.y, c.q2.x, c.q2.y};
+        s.bl[lane] = c.q2.z;
+        if (WITH_ID) s.id[lane] = c.id;
+    } else if (lane == n) {                                  // null record: opacity 0 -> alpha 0, T unchanged
         s.r0[n] = f4{0.f, 0.f, 0.f, 0.f};
         s.r1[n] = f4{0.f, 0.f, 0.f, 0.f};
         s.bl[n] = 0.f;
     }
     __syncthreads();
-    return n;
 }
 
 __device__ __forceinline__ int launch_priority(uint32_t b, uint32_t grid) {
@@ -618,13 +788,11 @@ __global__ __launch_bounds__(64) void raster_forward_kernel(const uint2* __restr
                                                             const Rec64* __restrict__ rec, const uint32_t* __restrict__ order,
                                                             int tiles_x, int H, int W, float chi, float alpha_max,
                                                             float alpha_cutoff, float* __restrict__ image,
-                                                            float* __restrict__ accum, uint32_t* __restrict__ visited,
-                                                            WaveStats* __restrict__ stats) {
+                                                            float* __restrict__ accum, WaveStats* __restrict__ stats, uint32_t id_max) {
     __shared__ RasterStage s;
     const int lane = threadIdx.x;
-    const uint32_t tile = order[blockIdx.x >> 1];
-    const int half = blockIdx.x & 1;
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const uint32_t list = order[blockIdx.x];
+    const int tx = list % tiles_x, hy = list / tiles_x;
     const int prio = launch_priority(blockIdx.x, gridDim.x);
     if (prio == 3) __builtin_amdgcn_s_setprio(3);
     else if (prio == 2) __builtin_amdgcn_s_setprio(2);
@@ -632,23 +800,23 @@ __global__ __launch_bounds__(64) void raster_forward_kernel(const uint2* __restr
     const unsigned long long t_begin = stats ? __builtin_amdgcn_s_memtime() : 0ull;
     uint32_t st_chunks = 0, st_visited = 0;
     const int px = tx * 16 + (lane & 15);
-    const int pya = ty * 16 + half * 8 + (lane >> 4), pyb = pya + 4;
+    const int pya = hy * 8 + (lane >> 4), pyb = pya + 4;
     const bool va = (px < W) && (pya < H), vb = (px < W) && (pyb < H);
     const float fpx = (float)px;
     const v2f fpy = {(float)pya, (float)pyb};
     v2f T = {va ? 1.0f : 0.0f, vb ? 1.0f : 0.0f};
     v2f Cr = {0.f, 0.f}, Cg = {0.f, 0.f}, Cb = {0.f, 0.f};
-    const float x0 = (float)(tx * 16), x1 = x0 + 15.0f, y0 = (float)(ty * 16 + half * 8), y1 = y0 + 7.0f;
-    const uint2 rg = ranges[tile];
+    const uint2 rg = ranges[list];
     const float chik = chi * QK;
     bool alive_any = __any(va || vb);
     uint32_t base = rg.x;
     Candidate cand;
-    if (alive_any && base < rg.y) cand = fetch_candidate(lane, base, rg.y, ids, rec);
+    if (alive_any && base < rg.y) cand = fetch_candidate(lane, base, rg.y, ids, rec, id_max);
     while (alive_any && base < rg.y) {
-        const int n = compact_candidates<false>(s, cand, x0, x1, y0, y1);
+        const int n = (int)min(rg.y - base, (uint32_t)BATCH);
+        stage_candidates<false>(s, cand, n, lane);
         base += BATCH;
-        if (base < rg.y) cand = fetch_candidate(lane, base, rg.y, ids, rec);   // in flight during the loop below
+        if (base < rg.y) cand = fetch_candidate(lane, base, rg.y, ids, rec, id_max);   // in flight during the loop below
         ++st_chunks;
         st_visited += (uint32_t)n;
         for (int j = 0; j < n; j += 2) {
@@ -678,12 +846,12 @@ __global__ __launch_bounds__(64) void raster_forward_kernel(const uint2* __restr
                 Cr += w0 * b0.z; Cg += w0 * b0.w; Cb += w0 * cb0;
                 Cr += w1 * b1.z; Cg += w1 * b1.w; Cb += w1 * cb1;
             }
+            if ((j & 14) == 14 && !__any(T.x > 5e-5f || T.y > 5e-5f)) break;       // every 16 entries: all pixels dead
         }
-        alive_any = __any(T.x > 5e-5f || T.y > 5e-5f);        // once per chunk: dead pixels stay dead
+        alive_any = __any(T.x > 5e-5f || T.y > 5e-5f);        // dead pixels stay dead
     }
-    if (visited && lane == 0) visited[tile * 2 + half] = st_visited;
     if (stats && lane == 0)
-        stats[tile * 2 + half] = WaveStats{rg.y - rg.x, st_chunks, st_visited, (uint32_t)(__builtin_amdgcn_s_memtime() - t_begin)};
+        stats[list] = WaveStats{rg.y - rg.x, st_chunks, st_visited, (uint32_t)(__builtin_amdgcn_s_memtime() - t_begin)};
     if (va) {
         const int64_t o = ((int64_t)pya * W + px) * 3;
         image[o + 0] = fminf(fmaxf(Cr.x, 0.0f), 1.0f); image[o + 1] = fminf(fmaxf(Cg.x, 0.0f), 1.0f);
@@ -749,12 +917,11 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
                                                              int tiles_x, int H, int W, float chi, float alpha_max,
                                                              float alpha_cutoff, const float* __restrict__ accum,
                                                              const float* __restrict__ gimg, float* __restrict__ grad2d,
-                                                             WaveStats* __restrict__ stats, int ablate) {
+                                                             WaveStats* __restrict__ stats, int ablate, uint32_t id_max) {
     __shared__ RasterStage s;
     const int lane = threadIdx.x;
-    const uint32_t tile = order[blockIdx.x >> 1];
-    const int half = blockIdx.x & 1;
-    const uint2 rg = ranges[tile];
+    const uint32_t list = order[blockIdx.x];
+    const uint2 rg = ranges[list];
     if (rg.x >= rg.y) return;
     const int prio = launch_priority(blockIdx.x, gridDim.x);
     if (prio == 3) __builtin_amdgcn_s_setprio(3);
@@ -762,9 +929,9 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
     else if (prio == 1) __builtin_amdgcn_s_setprio(1);
     const unsigned long long t_begin = stats ? __builtin_amdgcn_s_memtime() : 0ull;
     uint32_t st_chunks = 0, st_visited = 0;
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int tx = list % tiles_x, hy = list / tiles_x;
     const int px = tx * 16 + (lane & 15);
-    const int pya = ty * 16 + half * 8 + (lane >> 4), pyb = pya + 4;
+    const int pya = hy * 8 + (lane >> 4), pyb = pya + 4;
     const bool va = (px < W) && (pya < H), vb = (px < W) && (pyb < H);
     const float fpx = (float)px;
     const v2f fpy = {(float)pya, (float)pyb};
@@ -791,16 +958,16 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
         Gr = v2f{g[0][0], g[1][0]}; Gg = v2f{g[0][1], g[1][1]}; Gb = v2f{g[0][2], g[1][2]};
         suffix = v2f{sfx[0], sfx[1]};
     }
-    const float x0 = (float)(tx * 16), x1 = x0 + 15.0f, y0 = (float)(ty * 16 + half * 8), y1 = y0 + 7.0f;
     const float chik = chi * QK;
     bool alive_any = __any(va || vb);
     uint32_t base = rg.x;
     Candidate cand;
-    if (alive_any) cand = fetch_candidate(lane, base, rg.y, ids, rec);
+    if (alive_any) cand = fetch_candidate(lane, base, rg.y, ids, rec, id_max);
     while (alive_any && base < rg.y) {
-        const int n = compact_candidates<true>(s, cand, x0, x1, y0, y1);
+        const int n = (int)min(rg.y - base, (uint32_t)BATCH);
+        stage_candidates<true>(s, cand, n, lane);
         base += BATCH;
-        if (base < rg.y) cand = fetch_candidate(lane, base, rg.y, ids, rec);   // in flight during the loop below
+        if (base < rg.y) cand = fetch_candidate(lane, base, rg.y, ids, rec, id_max);   // in flight during the loop below
         ++st_chunks;
         st_visited += (uint32_t)n;
         for (int j = 0; j < n; ++j) {
@@ -858,11 +1025,12 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
                 }
             }
             T = T - al * T;
+            if ((j & 7) == 7 && !__any(T.x > 5e-5f || T.y > 5e-5f)) break;         // every 8 entries: all pixels dead
         }
-        alive_any = __any(T.x > 5e-5f || T.y > 5e-5f);        // once per chunk: dead pixels stay dead
+        alive_any = __any(T.x > 5e-5f || T.y > 5e-5f);        // dead pixels stay dead
     }
     if (stats && lane == 0)
-        stats[tile * 2 + half] = WaveStats{rg.y - rg.x, st_chunks, st_visited, (uint32_t)(__builtin_amdgcn_s_memtime() - t_begin)};
+        stats[list] = WaveStats{rg.y - rg.x, st_chunks, st_visited, (uint32_t)(__builtin_amdgcn_s_memtime() - t_begin)};
 }
 
 // ---- K8 ------------------------------------------------------------------------------------------
@@ -1016,23 +1184,26 @@ int gsplat_classify_counts(const gsplat_counts* c) {
     return GSPLAT_SCENE_OK;
 }
 
-int64_t gsplat_project_state_bytes(int64_t n) { return carve_project(nullptr, n > 0 ? n : 1).bytes; }
-
-int64_t gsplat_project_scratch_bytes(int64_t n) { return up((int64_t)scan_temp_bytes(n)) + ALIGN; }
-
-int64_t gsplat_bin_state_bytes(int64_t n_pairs, const gsplat_view* v) {
-    if (!v) return -1;
-    const int64_t nt = (int64_t)((v->W + 15) / 16) * ((v->H + 15) / 16);
-    return carve_bin(nullptr, n_pairs, nt).bytes;
+int64_t gsplat_project_state_bytes(int64_t n, const gsplat_view* v) {
+    if (!v || v->H <= 0 || v->W <= 0) return -1;
+    return carve_project(nullptr, n > 0 ? n : 1, n_lists(v)).bytes;
 }
 
-int64_t gsplat_bin_scratch_bytes(int64_t n, int64_t n_pairs) {
+int64_t gsplat_project_scratch_bytes(int64_t n) { (void)n; return ALIGN; }        // nothing needed since ABI 2
+
+int64_t gsplat_bin_state_bytes(int64_t n_binned, const gsplat_view* v) {
+    if (!v) return -1;
+    return up((n_binned > 0 ? n_binned : 1) * 4);                                   // sorted ids
+}
+
+int64_t gsplat_bin_scratch_bytes(int64_t n, int64_t n_binned) {
     (void)n;
-    return carve_bin_scratch(nullptr, n_pairs).bytes;
+    return carve_bin_scratch(nullptr, n_binned).bytes;
 }
 
 int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, void* project_state, void* scratch,
                    int64_t scratch_bytes, gsplat_counts* counts_host, void* stream_) {
+    (void)scratch; (void)scratch_bytes;
     bool fused = false;
     int rc = check_gaussians(g, &fused);
     if (rc) return rc;
@@ -1040,105 +1211,112 @@ int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_vie
     if (!c2w || !project_state) return fail(GSPLAT_ERR_BAD_ARG, "c2w / project_state is NULL");
     hipStream_t st = (hipStream_t)stream_;
     const int64_t n = g->n;
-    ProjectState ps = carve_project(project_state, n > 0 ? n : 1);
+    const int64_t nl = n_lists(v);
+    if (nl > 0x7fffffffLL) return fail(GSPLAT_ERR_BAD_ARG, "image too large");
+    ProjectState ps = carve_project(project_state, n > 0 ? n : 1, nl);
     const ViewK vk = make_viewk(*v);
-    hipLaunchKernelGGL(camera_kernel, dim3(1), dim3(COUNT_SHARDS), 0, st, c2w, ps.cam, ps.counts, ps.shards);
+    hipLaunchKernelGGL(camera_kernel, dim3(1), dim3(256), 0, st, c2w, ps.cam, ps.counts, ps.shards);
     LAUNCH_CHECK("camera_kernel");
     if (n > 0) {
-        Records out{ps.rec, ps.rect, ps.depth, ps.tiles};
+        Records out{ps.rec, ps.rect, ps.depth, ps.tiles, nullptr, nullptr};
         if (fused)
-            hipLaunchKernelGGL(project_kernel<true>, dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, vk, out, ps.shards);
+            hipLaunchKernelGGL(project_kernel<true>, dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, vk, out, ps.shards, ps.wave_off);
         else
-            hipLaunchKernelGGL(project_kernel<false>, dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, vk, out, ps.shards);
+            hipLaunchKernelGGL(project_kernel<false>, dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, vk, out, ps.shards, ps.wave_off);
         LAUNCH_CHECK("project_kernel");
-        size_t need = scan_temp_bytes(n);
-        if (!scratch || (int64_t)need > scratch_bytes) return fail(GSPLAT_ERR_WORKSPACE, "project scratch too small");
-        HIP_TRY(rocprim::inclusive_scan(scratch, need, ps.tiles, ps.offsets, (size_t)n, rocprim::plus<uint32_t>(), st));
-        hipLaunchKernelGGL(finish_counts_kernel, dim3(1), dim3(COUNT_SHARDS), 0, st, ps.offsets, n, ps.shards, ps.counts);
-        LAUNCH_CHECK("finish_counts_kernel");
     }
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, (int)blocks64(n), ps.wave_off, ps.shards, ps.counts);
+    LAUNCH_CHECK("scan_kernel");
     if (counts_host) HIP_TRY(hipMemcpyAsync(counts_host, ps.counts, sizeof(gsplat_counts), hipMemcpyDeviceToHost, st));
     return GSPLAT_OK;
 }
 
-int gsplat_bin(int64_t n, int64_t n_pairs, const gsplat_view* v, const void* project_state, void* bin_state, void* scratch,
+int gsplat_bin(int64_t n, int64_t n_binned, const gsplat_view* v, const void* project_state, void* bin_state, void* scratch,
                int64_t scratch_bytes, void* stream_) {
     int rc = check_view(v);
     if (rc) return rc;
-    if (n < 0 || n_pairs < 0 || n_pairs > 0xFFFFFFFFLL) return fail(GSPLAT_ERR_BAD_ARG, "n / n_pairs out of range");
+    if (n < 0 || n_binned < 0 || n_binned > 0xFFFFFFFFLL) return fail(GSPLAT_ERR_BAD_ARG, "n / n_binned out of range");
     if (!project_state || !bin_state) return fail(GSPLAT_ERR_BAD_ARG, "state is NULL");
     hipStream_t st = (hipStream_t)stream_;
     const ViewK vk = make_viewk(*v);
-    const int64_t nt = (int64_t)vk.tiles_x * vk.tiles_y;
-    ProjectState ps = carve_project((void*)project_state, n > 0 ? n : 1);
-    BinState bs = carve_bin(bin_state, n_pairs, nt);
-    HIP_TRY(hipMemsetAsync(bs.ranges, 0, nt * sizeof(uint2), st));
-    if (n_pairs == 0 || n == 0) {
-        hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, st, (int)nt, bs.ranges, (const uint32_t*)nullptr, bs.order_fwd);
-        LAUNCH_CHECK("order_tiles_kernel");
+    const int64_t nl = n_lists(v);
+    ProjectState ps = carve_project((void*)project_state, n > 0 ? n : 1, nl);
+    HIP_TRY(hipMemsetAsync(ps.ranges, 0, nl * sizeof(uint2), st));
+    if (n_binned == 0 || n == 0) {
+        hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, (int)nl, ps.ranges, ps.order, ps.class_bounds);
+        LAUNCH_CHECK("plan_kernel");
         return GSPLAT_OK;
     }
-    BinScratch sc = carve_bin_scratch(scratch, n_pairs);
+    BinScratch sc = carve_bin_scratch(scratch, n_binned);
     if (!scratch || sc.bytes > scratch_bytes) return fail(GSPLAT_ERR_WORKSPACE, "bin scratch too small");
-    hipLaunchKernelGGL(emit_pairs_kernel, dim3(blocks256(n)), dim3(256), 0, st, n, ps.depth, ps.rect, ps.tiles, ps.offsets, vk.tiles_x,
-                       n_pairs, sc.keys_in, sc.vals_in);
+    uint32_t* sorted_ids = (uint32_t*)bin_state;
+    hipLaunchKernelGGL(emit_pairs_kernel, dim3(blocks64(n)), dim3(64), 0, st, n, ps.depth, ps.rect, ps.tiles, ps.wave_off, vk.tiles_x,
+                       (uint32_t)n_binned, sc.keys_in, sc.vals_in);
     LAUNCH_CHECK("emit_pairs_kernel");
-    // F12 (tile part): radix sort on the tile-id bits only
-    unsigned tile_bits = 1;
-    while ((1LL << tile_bits) < nt) ++tile_bits;
+    // F12 (list part): radix sort on the list-id bits only
+    unsigned list_bits = 1;
+    while ((1LL << list_bits) < nl) ++list_bits;
     size_t tb = sc.temp_bytes;
-    HIP_TRY(rocprim::radix_sort_pairs(sc.temp, tb, sc.keys_in, sc.keys_out, sc.vals_in, sc.vals_out, (size_t)n_pairs, 0u, tile_bits,
+    HIP_TRY(rocprim::radix_sort_pairs(sc.temp, tb, sc.keys_in, sc.keys_out, sc.vals_in, sc.vals_out, (size_t)n_binned, 0u, list_bits,
                                       st));
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(blocks256(n_pairs)), dim3(256), 0, st, n_pairs, sc.keys_out, bs.ranges);
-    LAUNCH_CHECK("tile_ranges_kernel");
-    // F9 + F12 (depth part): per-tile sort by (depth, index)
-    hipLaunchKernelGGL((tile_sort_kernel<128, TILE_SORT_SMALL, false>), dim3((unsigned)nt), dim3(128), 0, st, bs.ranges, sc.vals_out,
-                       bs.sorted_ids);
-    LAUNCH_CHECK("tile_sort_kernel<small>");
-    hipLaunchKernelGGL((tile_sort_kernel<256, TILE_SORT_LDS, true>), dim3((unsigned)nt), dim3(256), 0, st, bs.ranges, sc.vals_out,
-                       bs.sorted_ids);
-    LAUNCH_CHECK("tile_sort_kernel<large>");
-    hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, st, (int)nt, bs.ranges, (const uint32_t*)nullptr, bs.order_fwd);
-    LAUNCH_CHECK("order_tiles_kernel");
+    hipLaunchKernelGGL(list_ranges_kernel, dim3(blocks256(n_binned)), dim3(256), 0, st, n_binned, sc.keys_out, ps.ranges);
+    LAUNCH_CHECK("list_ranges_kernel");
+    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, (int)nl, ps.ranges, ps.order, ps.class_bounds);
+    LAUNCH_CHECK("plan_kernel");
+    // F9 + F12 (depth part): per-list sort by (depth, index); one launch per size class, grids bounded by what the class
+    // can hold
+    uint64_t* vals = sc.vals_out;
+    const auto cap = [&](int64_t min_len) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(nl, n_binned / min_len)); };
+    if (n_binned >= 4096) {
+        hipLaunchKernelGGL(huge_sort_kernel, dim3(cap(4096)), dim3(256), 0, st, ps.order, ps.class_bounds, ps.ranges, vals, sorted_ids);
+        LAUNCH_CHECK("huge_sort_kernel");
+    }
+    if (n_binned >= 1024) {
+        hipLaunchKernelGGL((list_sort_kernel<256, 16, 12>), dim3(cap(1024)), dim3(256), 0, st, ps.order, ps.class_bounds, 1, ps.ranges,
+                           vals, sorted_ids);
+        LAUNCH_CHECK("list_sort_kernel<4096>");
+    }
+    if (n_binned >= 256) {
+        hipLaunchKernelGGL((list_sort_kernel<256, 4, 11>), dim3(cap(256)), dim3(256), 0, st, ps.order, ps.class_bounds, 2, ps.ranges,
+                           vals, sorted_ids);
+        LAUNCH_CHECK("list_sort_kernel<1024>");
+    }
+    hipLaunchKernelGGL((list_sort_kernel<64, 4, 9>), dim3(cap(1)), dim3(64), 0, st, ps.order, ps.class_bounds, 3, ps.ranges, vals,
+                       sorted_ids);
+    LAUNCH_CHECK("list_sort_kernel<256>");
     return GSPLAT_OK;
 }
 
-int gsplat_rasterize_forward(int64_t n, int64_t n_pairs, const gsplat_view* v, const void* project_state, const void* bin_state,
+int gsplat_rasterize_forward(int64_t n, int64_t n_binned, const gsplat_view* v, const void* project_state, const void* bin_state,
                              float* image, float* accum, void* stream_) {
+    (void)n_binned;
     int rc = check_view(v);
     if (rc) return rc;
     if (!project_state || !bin_state || !image) return fail(GSPLAT_ERR_BAD_ARG, "state / image is NULL");
     hipStream_t st = (hipStream_t)stream_;
     const ViewK vk = make_viewk(*v);
-    const int64_t nt = (int64_t)vk.tiles_x * vk.tiles_y;
-    ProjectState ps = carve_project((void*)project_state, n > 0 ? n : 1);
-    BinState bs = carve_bin((void*)bin_state, n_pairs, nt);
-    hipLaunchKernelGGL(raster_forward_kernel, dim3((unsigned)(2 * nt)), dim3(64), 0, st, bs.ranges, bs.sorted_ids, ps.rec,
-                       bs.order_fwd, vk.tiles_x, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, image, accum,
-                       accum ? bs.visited : (uint32_t*)nullptr, g_stats_fwd);
+    const int64_t nl = n_lists(v);
+    ProjectState ps = carve_project((void*)project_state, n > 0 ? n : 1, nl);
+    hipLaunchKernelGGL(raster_forward_kernel, dim3((unsigned)nl), dim3(64), 0, st, ps.ranges, (const uint32_t*)bin_state, ps.rec,
+                       ps.order, vk.tiles_x, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, image, accum, g_stats_fwd, (uint32_t)(n > 0 ? n - 1 : 0));
     LAUNCH_CHECK("raster_forward_kernel");
-    if (accum) {   // a backward pass will follow: order it by the work the forward actually did
-        hipLaunchKernelGGL(order_tiles_kernel, dim3(1), dim3(1024), 0, st, (int)nt, bs.ranges, bs.visited, bs.order_bwd);
-        LAUNCH_CHECK("order_tiles_kernel");
-    }
     return GSPLAT_OK;
 }
 
-int gsplat_rasterize_backward(int64_t n, int64_t n_pairs, const gsplat_view* v, const void* project_state, const void* bin_state,
+int gsplat_rasterize_backward(int64_t n, int64_t n_binned, const gsplat_view* v, const void* project_state, const void* bin_state,
                               const float* accum, const float* grad_image, float* grad2d, void* stream_) {
     int rc = check_view(v);
     if (rc) return rc;
     if (!project_state || !bin_state || !accum || !grad_image || !grad2d) return fail(GSPLAT_ERR_BAD_ARG, "NULL argument");
     hipStream_t st = (hipStream_t)stream_;
     const ViewK vk = make_viewk(*v);
-    const int64_t nt = (int64_t)vk.tiles_x * vk.tiles_y;
-    ProjectState ps = carve_project((void*)project_state, n > 0 ? n : 1);
-    BinState bs = carve_bin((void*)bin_state, n_pairs, nt);
+    const int64_t nl = n_lists(v);
+    ProjectState ps = carve_project((void*)project_state, n > 0 ? n : 1, nl);
     HIP_TRY(hipMemsetAsync(grad2d, 0, (size_t)(n > 0 ? n : 0) * 16 * sizeof(float), st));
-    if (n == 0 || n_pairs == 0) return GSPLAT_OK;
-    hipLaunchKernelGGL(raster_backward_kernel, dim3((unsigned)(2 * nt)), dim3(64), 0, st, bs.ranges, bs.sorted_ids, ps.rec,
-                       bs.order_bwd, vk.tiles_x, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, accum, grad_image,
-                       grad2d, g_stats_bwd, g_ablate);
+    if (n == 0 || n_binned == 0) return GSPLAT_OK;
+    hipLaunchKernelGGL(raster_backward_kernel, dim3((unsigned)nl), dim3(64), 0, st, ps.ranges, (const uint32_t*)bin_state, ps.rec,
+                       ps.order, vk.tiles_x, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, accum, grad_image,
+                       grad2d, g_stats_bwd, g_ablate, (uint32_t)(n - 1));
     LAUNCH_CHECK("raster_backward_kernel");
     return GSPLAT_OK;
 }
@@ -1155,7 +1333,7 @@ int gsplat_project_backward(const gsplat_gaussians* g, const float* c2w, const g
     if (fused && !(out->scale_raw && out->q_raw && out->f_dc && out->f_rest)) return fail(GSPLAT_ERR_BAD_ARG, "fused grads incomplete");
     if (!fused && !(out->color && out->sigma)) return fail(GSPLAT_ERR_BAD_ARG, "grad color / sigma is NULL");
     hipStream_t st = (hipStream_t)stream_;
-    ProjectState ps = carve_project((void*)project_state, g->n);
+    ProjectState ps = carve_project((void*)project_state, g->n, n_lists(v));
     const ViewK vk = make_viewk(*v);
     if (fused)
         hipLaunchKernelGGL(project_backward_kernel<true>, dim3(blocks64(g->n)), dim3(64), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out);

@@ -150,9 +150,9 @@ def _forward_impl(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad):
     H, W = view.H, view.W
     if n == 0:      # nothing survives by construction: the reference returns the zero image (render.py:109-112)
         fr.empty, fr.proj_state = True, None
-        return torch.zeros((H, W, 3), dtype=torch.float32, device=dev), fr, _abi.Counts(0, 0, 0, 0, 0)
+        return torch.zeros((H, W, 3), dtype=torch.float32, device=dev), fr, _abi.Counts(0, 0, 0, 0, 0, 0)
     with torch.cuda.device(dev):
-        fr.proj_state = torch.empty(lib.gsplat_project_state_bytes(n), dtype=torch.uint8, device=dev)
+        fr.proj_state = torch.empty(lib.gsplat_project_state_bytes(n, C.byref(view)), dtype=torch.uint8, device=dev)
         sbytes = lib.gsplat_project_scratch_bytes(n)
         scratch = _ws.get_scratch(dev, sbytes)
         pinned = _ws.get_pinned(dev)
@@ -171,7 +171,7 @@ def _forward_impl(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad):
             fr.empty = True
             fr.proj_state = None
             return image.zero_(), fr, counts
-        fr.n_pairs = int(counts.n_pairs)
+        fr.n_pairs = int(counts.n_binned)            # pairs actually binned (half-tile lists); counts.n_pairs = the reference's P
         fr.bin_state = torch.empty(lib.gsplat_bin_state_bytes(fr.n_pairs, C.byref(view)), dtype=torch.uint8, device=dev)
         sbytes = lib.gsplat_bin_scratch_bytes(n, fr.n_pairs)
         scratch = _ws.get_scratch(dev, sbytes)

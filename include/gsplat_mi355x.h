@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GSPLAT_ABI_VERSION 1
+#define GSPLAT_ABI_VERSION 2
 
 /* call status */
 #define GSPLAT_OK 0
@@ -96,9 +96,11 @@ typedef struct gsplat_gaussian_grads {
 typedef struct gsplat_counts {
     int32_t n_survivors;   /* pass the opacity prefilter, frustum cull and finite check              */
     int32_t n_visible;     /* ... and have an on-screen AABB  (V of SURVEY.md)                       */
-    int64_t n_pairs;       /* total (tile, Gaussian) pairs    (P of SURVEY.md)                       */
-    int32_t max_tiles_per_gaussian;
+    int64_t n_pairs;       /* the reference's (tile, Gaussian) pairs, F11  (P of SURVEY.md)          */
+    int32_t max_tiles_per_gaussian;   /* of the binned rectangles                                    */
     int32_t reserved;
+    int64_t n_binned;      /* (half-tile list, Gaussian) pairs actually binned: the tight box of each
+                              Gaussian over 16 x 8-pixel lists; sizes the gsplat_bin buffers          */
 } gsplat_counts;
 
 int gsplat_abi_version(void);
@@ -106,34 +108,36 @@ const char* gsplat_last_error(void);
 int gsplat_classify_counts(const gsplat_counts* counts_host);
 
 /* ---- buffer sizes (bytes) ---------------------------------------------------------------------- */
-int64_t gsplat_project_state_bytes(int64_t n);                         /* kept until the backward pass */
-int64_t gsplat_project_scratch_bytes(int64_t n);                       /* free after gsplat_project    */
-int64_t gsplat_bin_state_bytes(int64_t n_pairs, const gsplat_view* v); /* kept until the backward pass */
-int64_t gsplat_bin_scratch_bytes(int64_t n, int64_t n_pairs);          /* free after gsplat_bin        */
+int64_t gsplat_project_state_bytes(int64_t n, const gsplat_view* v);    /* kept until the backward pass */
+int64_t gsplat_project_scratch_bytes(int64_t n);                        /* free after gsplat_project    */
+int64_t gsplat_bin_state_bytes(int64_t n_binned, const gsplat_view* v); /* kept until the backward pass */
+int64_t gsplat_bin_scratch_bytes(int64_t n, int64_t n_binned);          /* free after gsplat_bin        */
 
 /* ---- forward ----------------------------------------------------------------------------------- */
 /* F1-F8, F10, F13 (+F2, F3 when fused): per-Gaussian projection, culls, EWA covariance, eigen clamp,
- * conic, tile rectangle, colour; then the prefix sum of tiles-per-Gaussian.  c2w is the DEVICE
- * [4,4] row-major camera-to-world matrix (no host read -> no synchronisation).  If counts_host is
- * not NULL the counters are copied there with hipMemcpyAsync on `stream`; the caller synchronises
- * the stream before reading them (it needs n_pairs to size the gsplat_bin buffers).                   */
+ * conic, tile rectangle, colour; counts the pairs of every half-tile list and plans the lists
+ * (offsets, launch order).  c2w is the DEVICE [4,4] row-major camera-to-world matrix (no host read ->
+ * no synchronisation).  If counts_host is not NULL the counters are copied there with hipMemcpyAsync
+ * on `stream`; the caller synchronises the stream before reading them (it needs n_binned to size the
+ * gsplat_bin buffers).                                                                                */
 int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, void* project_state,
                    void* scratch, int64_t scratch_bytes, gsplat_counts* counts_host, void* stream);
 
-/* F9, F11, F12: (tile, depth) keyed pair list, sorted; per-tile [start, end).  Order inside a tile is
- * (camera depth, Gaussian index) ascending.                                                           */
-int gsplat_bin(int64_t n, int64_t n_pairs, const gsplat_view* v, const void* project_state, void* bin_state,
+/* F9, F11, F12: every Gaussian is appended to the lists of its rectangle and every list is sorted;
+ * the order inside a list is (camera depth, Gaussian index) ascending.  The rendered image does not
+ * depend on the binning granularity, only on that order.                              */
+int gsplat_bin(int64_t n, int64_t n_binned, const gsplat_view* v, const void* project_state, void* bin_state,
                void* scratch, int64_t scratch_bytes, void* stream);
 
 /* F14, F15: per-tile front-to-back compositing.  image[H,W,3] receives clamp(C,0,1); accum[H,W,3]
  * (nullable; required for the backward pass) receives the unclamped C.                                */
-int gsplat_rasterize_forward(int64_t n, int64_t n_pairs, const gsplat_view* v, const void* project_state,
+int gsplat_rasterize_forward(int64_t n, int64_t n_binned, const gsplat_view* v, const void* project_state,
                              const void* bin_state, float* image, float* accum, void* stream);
 
 /* ---- backward ---------------------------------------------------------------------------------- */
 /* B1: gradient of the compositing w.r.t. the per-Gaussian 2D quantities.  grad2d is [n,16] floats
  * (u, v, conic a, b, c, opacity, r, g, b, pad...) and is zeroed by this call before accumulation.     */
-int gsplat_rasterize_backward(int64_t n, int64_t n_pairs, const gsplat_view* v, const void* project_state,
+int gsplat_rasterize_backward(int64_t n, int64_t n_binned, const gsplat_view* v, const void* project_state,
                               const void* bin_state, const float* accum, const float* grad_image,
                               float* grad2d, void* stream);
 

@@ -33,9 +33,9 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    # sizes the C side static_asserts / uses: gsplat_view 14 x 4 B, gsplat_counts 24 B, 9 and 8 pointer-sized fields
+    # sizes the C side static_asserts / uses: gsplat_view 14 x 4 B, gsplat_counts 32 B, 9 and 8 pointer-sized fields
     assert C.sizeof(abi.View) == 56
-    assert C.sizeof(abi.Counts) == 24
+    assert C.sizeof(abi.Counts) == 32
     assert C.sizeof(abi.Gaussians) == 9 * 8
     assert C.sizeof(abi.GaussianGrads) == 8 * 8
 
@@ -44,9 +44,11 @@ def test_size_queries_are_pure_host_functions():
     lib = abi.lib()
     v = abi.make_view(1080, 1920, 1100.0, 1100.0, 960.0, 540.0)
     n, p = 1_000_000, 2_720_508
-    assert lib.gsplat_project_state_bytes(n) >= n * 56
-    assert lib.gsplat_bin_state_bytes(p, C.byref(v)) >= p * 4 + 8160 * 8
-    assert lib.gsplat_bin_scratch_bytes(n, p) >= p * 20
+    lists = 120 * 135                                    # 16 x 8-pixel half-tile lists of a 1920 x 1080 image
+    assert lib.gsplat_project_state_bytes(n, C.byref(v)) >= n * 80 + lists * 12
+    assert lib.gsplat_project_state_bytes(n, None) == -1
+    assert lib.gsplat_bin_state_bytes(p, C.byref(v)) >= p * 4
+    assert lib.gsplat_bin_scratch_bytes(n, p) >= p * 8
     assert lib.gsplat_project_scratch_bytes(n) > 0
 
 

@@ -49,11 +49,14 @@ def _project(hm, d, arrs, fused=True, color=None, sigma=None):
     depth = np.zeros(n, np.float32)
     tiles = np.zeros(n, np.uint32)
     vis = np.zeros(n, np.int32)
+    brect = np.zeros((n, 2), np.uint32)
+    btiles = np.zeros(n, np.uint32)
     g = _gaussians(arrs, fused, color, sigma)
     c2w = np.ascontiguousarray(d["c2w"], np.float32)
-    hm.hm_project(C.byref(g), _ptr(c2w), C.byref(view), _ptr(rec64), _ptr(rect), _ptr(depth), _ptr(tiles), _ptr(vis))
+    hm.hm_project(C.byref(g), _ptr(c2w), C.byref(view), _ptr(rec64), _ptr(rect), _ptr(depth), _ptr(tiles), _ptr(vis),
+                  _ptr(brect), _ptr(btiles))
     assert np.array_equal(depth[vis == 0], rec64[vis == 0, 11])
-    rec = [rec64[:, 0:4], rec64[:, 4:8], rec64[:, 8:12], rect]
+    rec = [rec64[:, 0:4], rec64[:, 4:8], rec64[:, 8:12], rect, brect, btiles]
     return rec, tiles, vis, view, g, c2w
 
 
@@ -93,6 +96,27 @@ def test_forward_records_vs_reference_intermediates(hm, name):
     bad = (rect != d["im_tile_rect"]).any(1)
     assert bad.mean() <= 0.01, f"{bad.sum()} tile rectangles differ"
     assert np.all(tiles[ids] == (rect[:, 2] - rect[:, 0] + 1) * (rect[:, 3] - rect[:, 1] + 1))
+    # what the kernels bin: 16 x 8 half-tile lists of the tight box, inside the reference rectangle, and containing every
+    # pixel of the image with q <= chi (checked by brute force with the reference conic on the integer pixel grid)
+    bl, bh, bt = rec[4][ids, 0], rec[4][ids, 1], rec[5][ids]
+    br = np.stack([bl & 0xFFFF, bl >> 16, bh & 0xFFFF, bh >> 16], 1).astype(np.int32)
+    has = bt > 0
+    assert np.all(bt[has] == ((br[:, 2] - br[:, 0] + 1) * (br[:, 3] - br[:, 1] + 1))[has])
+    assert np.all((br[has, 0] >= rect[has, 0]) & (br[has, 2] <= rect[has, 2]) & (br[has, 1] >= 2 * rect[has, 1]) &
+                  (br[has, 3] <= 2 * rect[has, 3] + 1))
+    H, W = d["H"], d["W"]
+    ys, xs = np.mgrid[0:H, 0:W]
+    for k in range(0, len(ids), max(1, len(ids) // 60)):
+        du, dv = xs - float(d["im_u"][k]), ys - float(d["im_v"][k])
+        q = con[k, 0, 0] * du * du + 2 * con[k, 0, 1] * du * dv + con[k, 1, 1] * dv * dv
+        inside = q <= chi * (1 - 1e-6)
+        # the reference only renders the tiles of its own rectangle
+        inside &= (xs // 16 >= rect[k, 0]) & (xs // 16 <= rect[k, 2]) & (ys // 16 >= rect[k, 1]) & (ys // 16 <= rect[k, 3])
+        if not inside.any():
+            continue
+        assert bt[k] > 0, k
+        lx, ly = xs[inside] // 16, ys[inside] // 8
+        assert lx.min() >= br[k, 0] and lx.max() <= br[k, 2] and ly.min() >= br[k, 1] and ly.max() <= br[k, 3], k
 
 
 def _oracle_stage_grads(d, fused=True, color=None, sigma=None, seed=0):
@@ -138,7 +162,7 @@ def test_backward_fused_vs_oracle_autograd(hm, name):
     out = {k: np.full_like(arrs[k], np.nan) for k in util.PARAMS}
     gg = abi.GaussianGrads(_ptr(out["pos"]), _ptr(out["opacity_raw"]), None, None, _ptr(out["scale_raw"]),
                            _ptr(out["q_raw"]), _ptr(out["f_dc"]), _ptr(out["f_rest"]))
-    hm.hm_project_backward(C.byref(g), _ptr(c2w), C.byref(view), _ptr(tiles), _ptr(g2d), C.byref(gg))
+    hm.hm_project_backward(C.byref(g), _ptr(c2w), C.byref(view), _ptr(tiles), _ptr(g2d), C.byref(gg))   # tiles: visibility flag
     for k, r in zip(util.PARAMS, ref):
         util.check_grad(out[k], r, k)
 
@@ -154,7 +178,7 @@ def test_backward_unfused_vs_oracle_autograd(hm):
                color=np.full_like(color, np.nan), sigma=np.full_like(sigma, np.nan))
     gg = abi.GaussianGrads(_ptr(out["pos"]), _ptr(out["opacity_raw"]), _ptr(out["color"]), _ptr(out["sigma"]), None, None,
                            None, None)
-    hm.hm_project_backward(C.byref(g), _ptr(c2w), C.byref(view), _ptr(tiles), _ptr(g2d), C.byref(gg))
+    hm.hm_project_backward(C.byref(g), _ptr(c2w), C.byref(view), _ptr(tiles), _ptr(g2d), C.byref(gg))   # tiles: visibility flag
     for k, r in zip(("pos", "opacity_raw", "color", "sigma"), ref):
         util.check_grad(out[k], r, k)
 
