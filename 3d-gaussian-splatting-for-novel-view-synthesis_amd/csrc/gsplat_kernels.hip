@@ -734,11 +734,13 @@ int g_ablate = 0;      // diagnostics: bit 0 = no atomics, bit 1 = no wave reduc
 
 constexpr float QK = -0.72134752044448170368f;      // -0.5 * log2(e)
 
+constexpr int GROUP = 7;                             // backward: Gaussians per reduction group (7 x 9 = 63 sums <= 64 lanes)
+constexpr int BATCH_BWD = 63;                        // backward chunk: 9 groups
 struct RasterStage {
-    f4 r0[BATCH + 2];      // u, v, k A11, 2 k A12    (+2: null records that pad an odd entry count)
-    f4 r1[BATCH + 2];      // k A22, opacity, r, g
-    float bl[BATCH + 2];   // b
-    uint32_t id[BATCH + 2];
+    f4 r0[BATCH + 8];      // u, v, k A11, 2 k A12    (+: null records that pad a chunk to a multiple of 2 / of GROUP)
+    f4 r1[BATCH + 8];      // k A22, opacity, r, g
+    float bl[BATCH + 8];   // b
+    uint32_t id[BATCH + 8];
 };
 
 struct Candidate {         // one list entry held by one lane between fetch and staging
@@ -762,7 +764,8 @@ __device__ __forceinline__ Candidate fetch_candidate(int lane, uint32_t base, ui
     return c;
 }
 
-// Put the fetched entries into LDS, padded to an even count with a null record.  n = entries of this chunk (uniform).
+// Put the fetched entries into LDS, padded with null records (forward: to an even count; backward: to a multiple of
+// GROUP).  n = entries of this chunk (uniform).
 template <bool WITH_ID>
 __device__ __forceinline__ void stage_candidates(RasterStage& s, const Candidate& c, int n, int lane) {
     __syncthreads();       // previous chunk's LDS reads are done (single-wave block: orders LDS traffic only)
@@ -772,10 +775,11 @@ __device__ __forceinline__ void stage_candidates(RasterStage& s, const Candidate
         s.r1[lane] = f4{QK * c.q1.x, c.q1.y, c.q2.x, c.q2.y};
         s.bl[lane] = c.q2.z;
         if (WITH_ID) s.id[lane] = c.id;
-    } else if (lane == n) {                                  // null record: opacity 0 -> alpha 0, T unchanged
-        s.r0[n] = f4{0.f, 0.f, 0.f, 0.f};
-        s.r1[n] = f4{0.f, 0.f, 0.f, 0.f};
-        s.bl[n] = 0.f;
+    } else if (lane < n + (WITH_ID ? GROUP - 1 : 1)) {       // null records: opacity 0 -> alpha 0, T unchanged
+        s.r0[lane] = f4{0.f, 0.f, 0.f, 0.f};
+        s.r1[lane] = f4{0.f, 0.f, 0.f, 0.f};
+        s.bl[lane] = 0.f;
+        if (WITH_ID) s.id[lane] = 0u;
     }
     __syncthreads();
 }
@@ -866,46 +870,46 @@ __global__ __launch_bounds__(64) void raster_forward_kernel(const uint2* __restr
     }
 }
 
-// Nine per-lane partial sums -> their wave totals, total k delivered in lane k (k = 0..8) of row 0.
-// Reduce-scatter: two quad steps halve the number of live values (9 -> 5 -> 3) while summing over the quad (select +
-// DPP quad_perm add); then each lane's 3 values are summed over the 4 quads of its row (row_ror 4, 8), over the rows
-// (permlane16/32 swaps), and two DPP row shifts move values 1 and 2 next to value 0.  ~44 instructions against ~94
-// for nine independent butterfly reductions + readlane + select.
-__device__ __forceinline__ float reduce9_to_lanes(const float (&v)[9], int lane) {
-    const bool b0 = lane & 1, b1 = lane & 2;
-    float u[5], t[3];
+// 64 per-lane partial sums v[0..63] -> their wave totals, total i delivered in lane i: a reduce-scatter.  Every level
+// halves the number of live values while it sums over one more lane bit:
+//   lane bit 5: v_permlane32_swap(v[i], v[i + 32]) + add   (2 instructions per output)
+//   lane bit 4: v_permlane16_swap(v[i], v[i + 16]) + add   (2)
+//   lane bits 3..0: DPP add of each value with its partner lane (row_mirror, row_half_mirror, quad_perm), then a select
+//                   by the lane bit (3)
+// 141 instructions for 63 sums = 7 Gaussians x 9 gradients, against 7 x 44 for a 9-value reduction per Gaussian; and the
+// 63 totals leave in ONE atomic instruction (lane i adds total i) instead of seven.
+#define DPP_ADD_F32(x, ctrl) ((x) + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, 0xF, 0xF, false)))
+__device__ __forceinline__ float reduce_scatter64(float (&v)[64], int lane) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
-        const float lo = v[2 * i], hi = (2 * i + 1 < 9) ? v[2 * i + 1] : 0.0f;
-        const float keep = b0 ? hi : lo, send = b0 ? lo : hi;
-        u[i] = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0xB1, 0xF, 0xF, false));
+    for (int i = 0; i < 32; ++i) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 32]), false, false);
+        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);          // lanes 0-31: total of v[i]; lanes 32-63: of v[i + 32]
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const float lo = u[2 * j], hi = (2 * j + 1 < 5) ? u[2 * j + 1] : 0.0f;
-        const float keep = b1 ? hi : lo, send = b1 ? lo : hi;
-        t[j] = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x4E, 0xF, 0xF, false));
+    for (int i = 0; i < 16; ++i) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 16]), false, false);
+        v[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);          // even rows: v[i]; odd rows: v[i + 16]
     }
-    // lane (b1, b0) now holds, in t[j], the quad sum of component 4 j + 2 b1 + b0
+    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) t[j] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t[j]), 0x124, 0xF, 0xF, false));
-#pragma unroll
-    for (int j = 0; j < 3; ++j) t[j] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t[j]), 0x128, 0xF, 0xF, false));
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(t[j]), __float_as_uint(t[j]), false, false);
-        t[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    for (int i = 0; i < 8; ++i) {
+        const float x = DPP_ADD_F32(v[i], 0x140), y = DPP_ADD_F32(v[i + 8], 0x140);        // row_mirror: l <-> 15 - l
+        v[i] = b3 ? y : x;
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(t[j]), __float_as_uint(t[j]), false, false);
-        t[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    for (int i = 0; i < 4; ++i) {
+        const float x = DPP_ADD_F32(v[i], 0x141), y = DPP_ADD_F32(v[i + 4], 0x141);        // row_half_mirror: l <-> 7 - l
+        v[i] = b2 ? y : x;
     }
-    // lanes 4-7 take t[1] from lanes 0-3 (row_shr 4, bank 1), lanes 8-11 take t[2] from lanes 0-3 (row_shr 8, bank 2)
-    int out = __builtin_amdgcn_update_dpp(__float_as_int(t[0]), __float_as_int(t[1]), 0x114, 0xF, 0x2, false);
-    out = __builtin_amdgcn_update_dpp(out, __float_as_int(t[2]), 0x118, 0xF, 0x4, false);
-    return __int_as_float(out);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float x = DPP_ADD_F32(v[i], 0x4E), y = DPP_ADD_F32(v[i + 2], 0x4E);          // quad_perm [2,3,0,1]
+        v[i] = b1 ? y : x;
+    }
+    const float x = DPP_ADD_F32(v[0], 0xB1), y = DPP_ADD_F32(v[1], 0xB1);                  // quad_perm [1,0,3,2]
+    return b0 ? y : x;
 }
+#undef DPP_ADD_F32
 
 // K7: same traversal as K6 (identical T_i and alive decisions).  For pixel p and Gaussian i:
 //   d alpha_i = alive_i T_i (c_i . Gc) - (sum_{k>i} w_k (c_k . Gc)) / (1 - alpha_i),
@@ -963,69 +967,85 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
     uint32_t base = rg.x;
     Candidate cand;
     if (alive_any) cand = fetch_candidate(lane, base, rg.y, ids, rec, id_max);
+    const int my_g = lane / 9, my_k = lane - 9 * my_g;             // lane i adds gradient my_k of the group's Gaussian my_g
     while (alive_any && base < rg.y) {
-        const int n = (int)min(rg.y - base, (uint32_t)BATCH);
+        const int n = (int)min(rg.y - base, (uint32_t)BATCH_BWD);
         stage_candidates<true>(s, cand, n, lane);
-        base += BATCH;
+        base += BATCH_BWD;
         if (base < rg.y) cand = fetch_candidate(lane, base, rg.y, ids, rec, id_max);   // in flight during the loop below
         ++st_chunks;
         st_visited += (uint32_t)n;
-        for (int j = 0; j < n; ++j) {
-            const f4 a = s.r0[j], b = s.r1[j];
-            const float du = fpx - a.x;
-            const v2f dv = fpy - a.y;
-            const float c0 = a.z * du * du, c1 = a.w * du;
-            const v2f q = c0 + dv * (c1 + b.x * dv);                                   // k q  (k < 0)
-            const bool i0 = q.x >= chik, i1 = q.y >= chik;                              // q <= chi
-            if (!__any(i0 || i1)) continue;
-            const float cbl = s.bl[j], go = b.y;
-            v2f g;
-            g.x = __builtin_amdgcn_exp2f(q.x);
-            g.y = __builtin_amdgcn_exp2f(q.y);
-            const v2f og = go * g;
-            v2f al;
-            al.x = fminf(og.x, alpha_max); al.y = fminf(og.y, alpha_max);
-            al.x = (i0 && al.x >= alpha_cutoff) ? al.x : 0.0f; al.y = (i1 && al.y >= alpha_cutoff) ? al.y : 0.0f;
-            const bool act0 = (T.x > 5e-5f) && (al.x > 0.0f), act1 = (T.y > 5e-5f) && (al.y > 0.0f);
-            if (__any(act0 || act1)) {
-                v2f w = al * T;
-                w.x = act0 ? w.x : 0.0f; w.y = act1 ? w.y : 0.0f;
-                const v2f sdot = b.z * Gr + b.w * Gg + cbl * Gb;
-                const v2f ar = w * Gr, ag = w * Gg, ab = w * Gb;
-                suffix -= w * sdot;                                            // now the sum over k > i
-                v2f om = 1.0f - al;
-                om.x = __builtin_amdgcn_rcpf(om.x); om.y = __builtin_amdgcn_rcpf(om.y);   // 1 - alpha >= 0.01
-                v2f dal = T * sdot - suffix * om;
-                // clamp_max passes the gradient where o g <= alpha_max (render.py:372); alpha > 0 implies q <= chi
-                dal.x = (act0 && og.x <= alpha_max) ? dal.x : 0.0f;
-                dal.y = (act1 && og.y <= alpha_max) ? dal.y : 0.0f;
-                const v2f ao = dal * g;
-                const v2f dq = (-0.5f * go) * (g * dal);                       // dL/dq (q un-scaled)
-                const v2f dvq = dv * dq;
-                const float dqs = dq.x + dq.y, dvqs = dvq.x + dvq.y;
-                const v2f aA22 = dv * dvq;
-                // the staged conic is k * (A11, 2 A12, A22): undo the scale with 1/k for the two position gradients
-                const float r[9] = {-(2.0f * a.z * du * dqs + a.w * dvqs) * (1.0f / QK),        // d u
-                                    -(a.w * du * dqs + 2.0f * b.x * dvqs) * (1.0f / QK),        // d v
-                                    du * du * dqs,                                // d A11
-                                    2.0f * du * dvqs,                             // d A12
-                                    aA22.x + aA22.y,                              // d A22
-                                    ao.x + ao.y,                                  // d opacity
-                                    ar.x + ar.y, ag.x + ag.y, ab.x + ab.y};       // d rgb
+        for (int j0 = 0; j0 < n; j0 += GROUP) {
+            float v[64];
+            bool any_active = false;
+#pragma unroll
+            for (int gi = 0; gi < GROUP; ++gi) {
+                const int j = j0 + gi;
+                float* r = &v[gi * 9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) r[k] = 0.0f;
+                const f4 a = s.r0[j], b = s.r1[j];
+                const float du = fpx - a.x;
+                const v2f dv = fpy - a.y;
+                const float c0 = a.z * du * du, c1 = a.w * du;
+                const v2f q = c0 + dv * (c1 + b.x * dv);                                   // k q  (k < 0)
+                const bool i0 = q.x >= chik, i1 = q.y >= chik;                              // q <= chi
+                if (!__any(i0 || i1)) continue;
+                const float cbl = s.bl[j], go = b.y;
+                v2f g;
+                g.x = __builtin_amdgcn_exp2f(q.x);
+                g.y = __builtin_amdgcn_exp2f(q.y);
+                const v2f og = go * g;
+                v2f al;
+                al.x = fminf(og.x, alpha_max); al.y = fminf(og.y, alpha_max);
+                al.x = (i0 && al.x >= alpha_cutoff) ? al.x : 0.0f; al.y = (i1 && al.y >= alpha_cutoff) ? al.y : 0.0f;
+                const bool act0 = (T.x > 5e-5f) && (al.x > 0.0f), act1 = (T.y > 5e-5f) && (al.y > 0.0f);
+                if (__any(act0 || act1)) {
+                    any_active = true;
+                    v2f w = al * T;
+                    w.x = act0 ? w.x : 0.0f; w.y = act1 ? w.y : 0.0f;
+                    const v2f sdot = b.z * Gr + b.w * Gg + cbl * Gb;
+                    const v2f ar = w * Gr, ag = w * Gg, ab = w * Gb;
+                    suffix -= w * sdot;                                            // now the sum over k > i
+                    v2f om = 1.0f - al;
+                    om.x = __builtin_amdgcn_rcpf(om.x); om.y = __builtin_amdgcn_rcpf(om.y);   // 1 - alpha >= 0.01
+                    v2f dal = T * sdot - suffix * om;
+                    // clamp_max passes the gradient where o g <= alpha_max (render.py:372); alpha > 0 implies q <= chi
+                    dal.x = (act0 && og.x <= alpha_max) ? dal.x : 0.0f;
+                    dal.y = (act1 && og.y <= alpha_max) ? dal.y : 0.0f;
+                    const v2f ao = dal * g;
+                    const v2f dq = (-0.5f * go) * (g * dal);                       // dL/dq (q un-scaled)
+                    const v2f dvq = dv * dq;
+                    const float dqs = dq.x + dq.y, dvqs = dvq.x + dvq.y;
+                    const v2f aA22 = dv * dvq;
+                    // the staged conic is k * (A11, 2 A12, A22): undo the scale with 1/k for the two position gradients
+                    r[0] = -(2.0f * a.z * du * dqs + a.w * dvqs) * (1.0f / QK);    // d u
+                    r[1] = -(a.w * du * dqs + 2.0f * b.x * dvqs) * (1.0f / QK);    // d v
+                    r[2] = du * du * dqs;                                          // d A11
+                    r[3] = 2.0f * du * dvqs;                                       // d A12
+                    r[4] = aA22.x + aA22.y;                                        // d A22
+                    r[5] = ao.x + ao.y;                                            // d opacity
+                    r[6] = ar.x + ar.y; r[7] = ag.x + ag.y; r[8] = ab.x + ab.y;    // d rgb
+                }
+                T = T - al * T;
+            }
+            if (any_active) {
+                v[63] = 0.0f;
                 float mine;
                 if (ablate & 2) {
-                    mine = r[0] + r[1] + r[2] + r[3] + r[4] + r[5] + r[6] + r[7] + r[8];
+                    mine = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 63; ++k) mine += v[k];
                 } else {
-                    mine = reduce9_to_lanes(r, lane);
+                    mine = reduce_scatter64(v, lane);
                 }
                 if (ablate & 1) {
                     asm volatile("" ::"v"(mine));
-                } else if (lane < 9) {
-                    atomicAdd(&grad2d[(int64_t)s.id[j] * 16 + lane], mine);
+                } else if (mine != 0.0f && lane < GROUP * 9) {
+                    atomicAdd(&grad2d[(int64_t)s.id[j0 + my_g] * 16 + my_k], mine);
                 }
             }
-            T = T - al * T;
-            if ((j & 7) == 7 && !__any(T.x > 5e-5f || T.y > 5e-5f)) break;         // every 8 entries: all pixels dead
+            if (!__any(T.x > 5e-5f || T.y > 5e-5f)) break;                        // all pixels dead
         }
         alive_any = __any(T.x > 5e-5f || T.y > 5e-5f);        // dead pixels stay dead
     }
