@@ -235,12 +235,29 @@ __global__ __launch_bounds__(256) void camera_kernel(const float* __restrict__ c
 // 64 contiguous rows into LDS with fully coalesced 16-byte accesses and every lane then reads its row from LDS
 // (row strides 3, 4, 9, 45 words are conflict-free or 2-way at worst).  The SH block (f_dc + f_rest, 192 of the 236
 // input bytes) is only fetched when at least one Gaussian of the wave survived the culls.
+// Full 64-row blocks go global -> LDS directly (global_load_lds_dwordx4, gfx950): no VGPR round trip, and a wave can put
+// all of its ~15 KB of inputs in flight at once and wait for them once (the kernels run at 8-10 waves per CU, so bytes
+// in flight per wave are what buys bandwidth).  One such instruction writes 64 lanes x 16 B contiguously at a
+// wave-uniform LDS base: exactly the row-block image.  The caller's __syncthreads() (vmcnt(0) + barrier) retires them.
+// The last, partial block of an array takes the register path.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
 template <int R>
 __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float* __restrict__ g, int64_t row0, int64_t n, int lane) {
     const int64_t left = n - row0;
-    const int total = (int)(left < 64 ? left : 64) * R;       // floats to copy
     const float* __restrict__ src = g + row0 * R;             // 16-B aligned: row0 % 64 == 0, base 16-B aligned (host checks)
     constexpr int PIECES = 64 * R / 4;
+    if (left >= 64) {
+#pragma unroll
+        for (int it = 0; it < (PIECES + 63) / 64; ++it) {
+            const int piece = it * 64 + lane;
+            if (piece < PIECES)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + piece * 4), (lds_ptr_t)(lds + it * 256), 16, 0, 0);
+        }
+        return;
+    }
+    const int total = (int)left * R;       // floats to copy
 #pragma unroll
     for (int it = 0; it < (PIECES + 63) / 64; ++it) {
         const int piece = it * 64 + lane;
@@ -349,6 +366,10 @@ __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const C
     const int64_t row0 = (int64_t)blockIdx.x * 64, i = row0 + lane;
     const Camera cam = *camp;
     stage_geometry<FUSED>(s, g, row0, lane);
+    if (FUSED) {                                             // all inputs of the wave in flight at once, one wait
+        stage_rows<3>(s_dc, g.f_dc, row0, g.n, lane);
+        stage_rows<45>(s_rest, g.f_rest, row0, g.n, lane);
+    }
     __syncthreads();
     GaussIn in;
     Proj o;
@@ -360,12 +381,7 @@ __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const C
     RecOut r;
     r.vis = o.vis; r.tiles = 0; r.ref_tiles = 0; r.rect = u2{0u, 0u}; r.ref_rect = u2{0u, 0u};
     if (FUSED) {
-        if (__any(o.vis == VIS_OK)) {                        // wave-uniform: skip 192 B / Gaussian when all are culled
-            stage_rows<3>(s_dc, g.f_dc, row0, g.n, lane);
-            stage_rows<45>(s_rest, g.f_rest, row0, g.n, lane);
-            __syncthreads();
-            if (o.vis == VIS_OK) r = project_finish(in, o, true, ShCoefLds{s_dc + lane * 3, s_rest + lane * 45}, cam);
-        }
+        if (o.vis == VIS_OK) r = project_finish(in, o, true, ShCoefLds{s_dc + lane * 3, s_rest + lane * 45}, cam);
     } else if (o.vis == VIS_OK) {
         r = project_finish(in, o, false, ShCoefLds{nullptr, nullptr}, cam);
     }
