@@ -96,8 +96,9 @@ GS_HD Proj project_geometry(const GaussIn& in, bool fused, const Camera& cam, co
 }
 
 // K1 core, part 2: colour of a visible Gaussian (SH when fused) and the record.
+// with_colour = false (fused inputs only): the SH colour is filled in later by colour_kernel; rgb = 0 here.
 template <class Coef>
-GS_HD RecOut project_finish(const GaussIn& in, const Proj& o, bool fused, Coef coef, const Camera& cam) {
+GS_HD RecOut project_finish(const GaussIn& in, const Proj& o, bool fused, Coef coef, const Camera& cam, bool with_colour = true) {
     RecOut r;
     r.vis = o.vis;
     r.tiles = 0;
@@ -106,11 +107,13 @@ GS_HD RecOut project_finish(const GaussIn& in, const Proj& o, bool fused, Coef c
     r.ref_rect = u2{0u, 0u};
     r.ref_tiles = 0;
     if (o.vis == VIS_OK) {
-        float rgb[3];
+        float rgb[3] = {0.f, 0.f, 0.f};
         if (fused) {
-            ShMid sm;
-            sh_basis(in.p, cam.eye, sm);
-            sh_colour(sm, coef, rgb);
+            if (with_colour) {
+                ShMid sm;
+                sh_basis(in.p, cam.eye, sm);
+                sh_colour(sm, coef, rgb);
+            }
         } else {
             rgb[0] = in.col[0]; rgb[1] = in.col[1]; rgb[2] = in.col[2];
         }

@@ -356,17 +356,19 @@ __device__ __forceinline__ void for_each_list(u2 rect, uint32_t nt, int tiles_x,
     }
 }
 
-template <bool FUSED>
+// COLOUR = false (fused inputs): geometry only, 44 of the 236 input bytes; colour_kernel evaluates the SH colour later,
+// queued behind the copy of the counters so that it runs while the host reads them and sizes the binning buffers.
+template <bool FUSED, bool COLOUR>
 __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const Camera* __restrict__ camp, ViewK vk, Records out,
                                                      CountShard* shards, uint32_t* __restrict__ wave_pairs) {
     __shared__ ProjectLds s;
-    __shared__ float s_dc[FUSED ? 64 * 3 : 4];
-    __shared__ float s_rest[FUSED ? 64 * 45 : 4];
+    __shared__ float s_dc[FUSED && COLOUR ? 64 * 3 : 4];
+    __shared__ float s_rest[FUSED && COLOUR ? 64 * 45 : 4];
     const int lane = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * 64, i = row0 + lane;
     const Camera cam = *camp;
     stage_geometry<FUSED>(s, g, row0, lane);
-    if (FUSED) {                                             // all inputs of the wave in flight at once, one wait
+    if (FUSED && COLOUR) {                                   // all inputs of the wave in flight at once, one wait
         stage_rows<3>(s_dc, g.f_dc, row0, g.n, lane);
         stage_rows<45>(s_rest, g.f_rest, row0, g.n, lane);
     }
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const C
     RecOut r;
     r.vis = o.vis; r.tiles = 0; r.ref_tiles = 0; r.rect = u2{0u, 0u}; r.ref_rect = u2{0u, 0u};
     if (FUSED) {
-        if (o.vis == VIS_OK) r = project_finish(in, o, true, ShCoefLds{s_dc + lane * 3, s_rest + lane * 45}, cam);
+        if (o.vis == VIS_OK) r = project_finish(in, o, true, ShCoefLds{s_dc + lane * 3, s_rest + lane * 45}, cam, COLOUR);
     } else if (o.vis == VIS_OK) {
         r = project_finish(in, o, false, ShCoefLds{nullptr, nullptr}, cam);
     }
@@ -411,6 +413,32 @@ __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const C
         if (refp) atomicAdd(&sh->ref_pairs, refp);
         if (binp) atomicAdd(&sh->bin_pairs, binp);
         wave_pairs[blockIdx.x] = binp;            // scanned by scan_kernel -> where this block's pairs start
+    }
+}
+
+// ---- K1b: SH colour (fused inputs) -------------------------------------------------------------------
+// F3 for the Gaussians that were binned: 192 of the 236 input bytes per Gaussian are SH coefficients.  Writes r, g, b into
+// the record line the geometry pass left (z stays).
+__global__ __launch_bounds__(64) void colour_kernel(gsplat_gaussians g, const Camera* __restrict__ camp, const uint32_t* __restrict__ tiles,
+                                                    Rec64* __restrict__ rec) {
+    __shared__ float s_pos[64 * 3], s_dc[64 * 3], s_rest[64 * 45];
+    const int lane = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * 64, i = row0 + lane;
+    const bool need = i < g.n && tiles[i] != 0u;
+    if (!__any(need)) return;                                // wave-uniform: skip 204 B / Gaussian when none is binned
+    stage_rows<3>(s_pos, g.pos, row0, g.n, lane);
+    stage_rows<3>(s_dc, g.f_dc, row0, g.n, lane);
+    stage_rows<45>(s_rest, g.f_rest, row0, g.n, lane);
+    const Camera cam = *camp;
+    __syncthreads();
+    if (need) {
+        const float p[3] = {s_pos[lane * 3], s_pos[lane * 3 + 1], s_pos[lane * 3 + 2]};
+        ShMid sm;
+        sh_basis(p, cam.eye, sm);
+        float rgb[3];
+        sh_colour(sm, ShCoefLds{s_dc + lane * 3, s_rest + lane * 45}, rgb);
+        float* r2 = reinterpret_cast<float*>(&rec[i].r2);
+        r2[0] = rgb[0]; r2[1] = rgb[1]; r2[2] = rgb[2];
     }
 }
 
@@ -1238,7 +1266,7 @@ int64_t gsplat_bin_scratch_bytes(int64_t n, int64_t n_binned) {
 }
 
 int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, void* project_state, void* scratch,
-                   int64_t scratch_bytes, gsplat_counts* counts_host, void* stream_) {
+                   int64_t scratch_bytes, gsplat_counts* counts_host, void* counts_event, void* stream_) {
     (void)scratch; (void)scratch_bytes;
     bool fused = false;
     int rc = check_gaussians(g, &fused);
@@ -1256,14 +1284,19 @@ int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_vie
     if (n > 0) {
         Records out{ps.rec, ps.rect, ps.depth, ps.tiles, nullptr, nullptr};
         if (fused)
-            hipLaunchKernelGGL(project_kernel<true>, dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, vk, out, ps.shards, ps.wave_off);
+            hipLaunchKernelGGL((project_kernel<true, false>), dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, vk, out, ps.shards, ps.wave_off);
         else
-            hipLaunchKernelGGL(project_kernel<false>, dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, vk, out, ps.shards, ps.wave_off);
+            hipLaunchKernelGGL((project_kernel<false, true>), dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, vk, out, ps.shards, ps.wave_off);
         LAUNCH_CHECK("project_kernel");
     }
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, (int)blocks64(n), ps.wave_off, ps.shards, ps.counts);
     LAUNCH_CHECK("scan_kernel");
     if (counts_host) HIP_TRY(hipMemcpyAsync(counts_host, ps.counts, sizeof(gsplat_counts), hipMemcpyDeviceToHost, st));
+    if (counts_event) HIP_TRY(hipEventRecord((hipEvent_t)counts_event, st));
+    if (n > 0 && fused) {           // runs while the host waits for the counters and sizes the binning buffers
+        hipLaunchKernelGGL(colour_kernel, dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, ps.tiles, ps.rec);
+        LAUNCH_CHECK("colour_kernel");
+    }
     return GSPLAT_OK;
 }
 

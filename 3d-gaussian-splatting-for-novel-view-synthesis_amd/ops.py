@@ -54,6 +54,17 @@ class _Workspace:
     def __init__(self):
         self.scratch = {}
         self.pinned = {}
+        self.events = {}
+
+    def get_event(self, device):
+        """One reusable event per device: gsplat_project records it right behind the copy of the counters."""
+        key = (device.type, device.index)
+        ev = self.events.get(key)
+        if ev is None:
+            ev = torch.cuda.Event(enable_timing=False, blocking=False)
+            ev.record(torch.cuda.current_stream(device))          # events are created lazily: force the handle to exist
+            self.events[key] = ev
+        return ev
 
     def get_scratch(self, device, nbytes):
         key = (device.type, device.index)
@@ -156,12 +167,15 @@ def _forward_impl(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad):
         sbytes = lib.gsplat_project_scratch_bytes(n)
         scratch = _ws.get_scratch(dev, sbytes)
         pinned = _ws.get_pinned(dev)
+        ready = _ws.get_event(dev)
         with _stage("project"):
             _abi.check(lib.gsplat_project(C.byref(g), _p(c2w32), C.byref(view), _p(fr.proj_state), _p(scratch),
-                                          scratch.numel(), C.c_void_p(pinned.data_ptr()), st), "gsplat_project")
-        # the one host synchronisation of the forward pass: the pair count sizes the binning buffers, and the
-        # reference's empty / off-screen conventions need the survivor counts
-        torch.cuda.current_stream(dev).synchronize()
+                                          scratch.numel(), C.c_void_p(pinned.data_ptr()), C.c_void_p(ready.cuda_event), st),
+                       "gsplat_project")
+        # the one host wait of the forward pass: the pair count sizes the binning buffers, and the reference's empty /
+        # off-screen conventions need the survivor counts.  Only the counters are waited for: with fused inputs the SH
+        # colour pass is queued behind them and runs during this round trip.
+        ready.synchronize()
         counts = _abi.Counts.from_buffer_copy(pinned.numpy().tobytes())
         scene = lib.gsplat_classify_counts(C.byref(counts))
         if scene == _abi.GSPLAT_SCENE_ALL_OFFSCREEN:

@@ -62,7 +62,7 @@ def test_scene_classification_mirrors_reference_conventions():
 def test_bad_arguments_are_rejected_without_touching_the_gpu():
     lib = abi.lib()
     v = abi.make_view(64, 64, 50.0, 50.0, 32.0, 32.0)
-    assert lib.gsplat_project(None, None, C.byref(v), None, None, 0, None, None) == 1
+    assert lib.gsplat_project(None, None, C.byref(v), None, None, 0, None, None, None) == 1
     assert b"NULL" in lib.gsplat_last_error()
     v8 = abi.make_view(64, 64, 50.0, 50.0, 32.0, 32.0, T=8)
     assert lib.gsplat_bin(0, 0, C.byref(v8), None, None, None, 0, None) == 1
