@@ -208,3 +208,58 @@ def test_long_tile_lists_take_the_global_sort_path(gs):
     util.check_image(img.detach().cpu().numpy(), ref.detach().numpy(), frac=0.99)
     for k in util.PARAMS:
         util.check_grad(p[k].grad.cpu().numpy(), p64[k].grad.numpy(), k)
+
+
+def _vs_oracle(gs, s, cam, c2w, w, z_order_eps=None, frac=0.99):
+    p64 = {k: v.double() for k, v in s.items()}
+    if z_order_eps is not None:            # make (depth, index) the unique order in float64: the HIP path's tie rule
+        p64["pos"] = p64["pos"].clone()
+        p64["pos"][:, 2] += torch.arange(len(p64["pos"]), dtype=torch.float64) * z_order_eps
+    p64 = {k: v.requires_grad_(True) for k, v in p64.items()}
+    ref = tp.render_fused(p64["pos"], p64["f_dc"], p64["f_rest"], p64["opacity_raw"], p64["scale_raw"], p64["q_raw"],
+                          c2w.double(), *cam)
+    (ref * w.double()).sum().backward()
+    p = {k: v.to(DEV).requires_grad_(True) for k, v in s.items()}
+    img = gs.render_gaussians(p["pos"], p["f_dc"], p["f_rest"], p["opacity_raw"], p["scale_raw"], p["q_raw"], c2w.to(DEV), *cam)
+    (img * w.to(DEV)).sum().backward()
+    util.check_image(img.detach().cpu().numpy(), ref.detach().numpy(), frac=frac)
+    for k in util.PARAMS:
+        util.check_grad(p[k].grad.cpu().numpy(), p64[k].grad.numpy(), k)
+    return img
+
+
+def test_equal_depths_are_ordered_by_index(gs):
+    """Every Gaussian at the same camera depth: the per-list distribution sort sees one dense bucket and takes its exact
+    fallback, and the order inside a list must be the Gaussian index.  Lists of 1000+ entries."""
+    n, H, W, f = 3000, 32, 48, 40.0
+    g = torch.Generator().manual_seed(21)
+    z = torch.full((n,), 4.0, dtype=torch.float64)
+    uv = torch.stack([torch.rand(n, generator=g, dtype=torch.float64) * (W - 8) + 4,
+                      torch.rand(n, generator=g, dtype=torch.float64) * (H - 8) + 4], 1)
+    pos = torch.stack([(uv[:, 0] - W / 2) / f * z, (uv[:, 1] - H / 2) / f * z, z], 1).float()
+    assert float((pos[:, 2] - 4.0).abs().max()) == 0.0
+    s = dict(pos=pos, scale_raw=torch.randn(n, 3, generator=g) * 0.2 - 1.2, q_raw=torch.randn(n, 4, generator=g),
+             opacity_raw=torch.randn(n, generator=g) * 0.3 - 3.4, f_dc=torch.randn(n, 3, generator=g),
+             f_rest=torch.randn(n, 45, generator=g) * 0.2)
+    w = torch.rand(H, W, 3, generator=g)
+    _vs_oracle(gs, s, (H, W, f, f, W / 2.0, H / 2.0), torch.eye(4), w, z_order_eps=1e-10)
+    assert gs.render_stats()[2] > 0
+
+
+def test_huge_gaussians_cover_many_lists(gs):
+    """Gaussians whose rectangle spans more than 32 half-tile lists are binned by the whole wave (for_each_list)."""
+    n, H, W, f = 400, 120, 160, 100.0
+    g = torch.Generator().manual_seed(22)
+    z = torch.rand(n, generator=g, dtype=torch.float64) * 3 + 3
+    zs, order = torch.sort(z)
+    keep = torch.ones(n, dtype=torch.bool)
+    keep[order[1:][(zs[1:] - zs[:-1]) < 2e-5]] = False
+    uv = torch.stack([torch.rand(n, generator=g, dtype=torch.float64) * W, torch.rand(n, generator=g, dtype=torch.float64) * H], 1)
+    pos = torch.stack([(uv[:, 0] - W / 2) / f * z, (uv[:, 1] - H / 2) / f * z, z], 1).float()
+    scale = torch.randn(n, 3, generator=g) * 0.3 - 2.0
+    scale[::8] += 2.3                                  # every 8th: sigma ~ 1.3 world units = 30+ pixels -> 75+ px radius
+    s = dict(pos=pos, scale_raw=scale, q_raw=torch.randn(n, 4, generator=g), opacity_raw=torch.randn(n, generator=g) - 1.0,
+             f_dc=torch.randn(n, 3, generator=g), f_rest=torch.randn(n, 45, generator=g) * 0.2)
+    s = {k: v[keep].contiguous() for k, v in s.items()}
+    w = torch.rand(H, W, 3, generator=g)
+    _vs_oracle(gs, s, (H, W, f, f * 1.1, W / 2.0 + 1.5, H / 2.0 - 2.0), torch.tensor(scenes.orbit_c2w(0, 8)), w)
