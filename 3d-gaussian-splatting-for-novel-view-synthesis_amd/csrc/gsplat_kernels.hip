@@ -1,25 +1,24 @@
 // gsplat_kernels.hip -- MI355X (gfx950, wave64) kernels and the C ABI of include/gsplat_mi355x.h.
 //
 // Pipeline (stage ids of SURVEY.md §8a in brackets):
-//   K0 camera_kernel            c2w (device) -> Camera block                         [F5 setup]
-//   K1 project_kernel           per Gaussian: culls, EWA, eigen clamp, conic, rect   [F1-F8, F10, F13]
-//   K2 rocprim inclusive_scan   tiles-per-Gaussian -> pair offsets                   [F11]
-//   K3 emit_pairs_kernel        key = tile id, payload = depth bits << 32 | id        [F11]
-//   K4 rocprim radix_sort_pairs radix sort on the tile-id bits only (2 passes)       [F12]
-//   K4b tile_sort_kernel        per-tile bitonic sort of the payloads in LDS          [F9, F12]
-//   K5 tile_ranges_kernel       per-tile [start, end)                                [F12]
-//   K6 raster_forward_kernel    one wave64 per 16x8 half tile, 2 pixels per lane     [F14, F15]
-//   K7 raster_backward_kernel   same traversal, analytic gradients, wave reduction   [B1]
-//   K8 project_backward_kernel  chain rule to the reference's input tensors          [B2, B3]
+//   K0  camera_kernel          c2w (device) -> Camera block, zero counters                      [F5 setup]
+//   K1  project_kernel         per Gaussian: culls, EWA, eigen clamp, conic, rectangles         [F1-F8, F10, F13]
+//   K1b colour_kernel          SH colour of the binned Gaussians (fused inputs)                 [F3]
+//   K2  finish_counts_kernel   totals of the sharded counters -> gsplat_counts
+//   K3  bin_count / bin_scatter / bin_local_kernel   two-level counting sort of the (list, Gaussian) pairs by list  [F11, F12]
+//   K4  list_sort_kernel       per-list depth sort in LDS (huge_sort_kernel: in global memory)  [F9, F12]
+//   K5  plan_kernel            longest-first launch order of the lists, sort size classes
+//   K6  raster_forward_kernel  one wave64 per 16x8 half tile = list, 2 pixels per lane          [F14, F15]
+//   K7  raster_backward_kernel same traversal, analytic gradients, 63-value reduce-scatter      [B1]
+//   K8  project_backward_kernel chain rule to the reference's input tensors                     [B2, B3]
 //
-// No MFMA: there is no dense contraction on this path.  No CPU fallback: without a GPU every entry
-// point returns GSPLAT_ERR_HIP.
+// Everything is hand-written HIP for gfx950; no library kernels.  No MFMA: there is no dense contraction on this path.
+// No CPU fallback: without a GPU every entry point returns GSPLAT_ERR_HIP.
 #include <cstdio>
 #include <cstring>
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "gs_body.h"
 
@@ -64,6 +63,13 @@ constexpr int COUNT_SHARDS = 256;     // per-wave counters are spread over 256 c
 struct alignas(64) CountShard { int32_t survivors, visible, max_tiles; uint32_t ref_pairs, bin_pairs; int32_t pad[11]; };
 
 // A "list" is the depth-ordered set of Gaussians of one HALF tile (16 x 8 pixels): the unit one wave64 rasterises.
+// Binning is a two-level counting sort: (list, Gaussian) pairs go to coarse bins of 64 consecutive lists first
+// (bin_count_kernel / bin_scatter_kernel, blocks of 2048 Gaussians with an LDS histogram, one global atomic per block and
+// bin), then every bin is split into its 64 lists in LDS (bin_local_kernel), then every list is sorted by depth.
+constexpr int BIN_SHIFT = 6;                 // 64 lists per coarse bin
+constexpr int BIN_GAUSS = 2048;              // Gaussians per block of bin_count_kernel / bin_scatter_kernel
+constexpr int MAX_BINS = 8192;               // LDS histogram of the two kernels (32 KB): images up to 8192 x 8192 / 128 lists
+
 struct ProjectState {
     Camera* cam;
     DevCounts* counts;
@@ -72,7 +78,9 @@ struct ProjectState {
     u2* rect;                // per Gaussian: inclusive rectangle of lists
     float* depth;
     uint32_t* tiles;         // per Gaussian: number of lists (0 = contributes nowhere)
-    uint32_t* wave_off;      // [ceil(n / 64)] pairs of each 64-Gaussian block, then (scan_kernel) their exclusive prefix
+    uint32_t* bin_total;     // [bins] pairs per coarse bin
+    uint32_t* bin_start;     // [bins + 1] exclusive prefix of bin_total
+    uint32_t* block_off;     // [blocks x bins] where a block's pairs start inside a bin
     uint2* ranges;           // [lists] start, end in the pair arrays
     uint32_t* order;         // [lists] launch order: longest list first
     uint32_t* class_bounds;  // [8] boundaries of the sort size classes inside `order`
@@ -80,11 +88,14 @@ struct ProjectState {
 };
 
 inline int64_t n_lists(const gsplat_view* v) { return (int64_t)((v->W + 15) / 16) * ((v->H + 7) / 8); }
+inline int64_t n_bins(int64_t nl) { return (nl + (1 << BIN_SHIFT) - 1) >> BIN_SHIFT; }
+inline int64_t n_bin_blocks(int64_t n) { return (n + BIN_GAUSS - 1) / BIN_GAUSS; }
 
 ProjectState carve_project(void* base, int64_t n, int64_t nl) {
     ProjectState s;
     char* p = (char*)base;
     int64_t o = 0;
+    const int64_t nb = n_bins(nl);
     s.cam = (Camera*)(p + o); o += up(sizeof(Camera));
     s.counts = (DevCounts*)(p + o); o += up(sizeof(DevCounts));
     s.shards = (CountShard*)(p + o); o += up(sizeof(CountShard) * COUNT_SHARDS);
@@ -92,7 +103,9 @@ ProjectState carve_project(void* base, int64_t n, int64_t nl) {
     s.rect = (u2*)(p + o); o += up(n * 8);
     s.depth = (float*)(p + o); o += up(n * 4);
     s.tiles = (uint32_t*)(p + o); o += up(n * 4);
-    s.wave_off = (uint32_t*)(p + o); o += up((n + 63) / 64 * 4);
+    s.bin_total = (uint32_t*)(p + o); o += up(nb * 4);
+    s.bin_start = (uint32_t*)(p + o); o += up((nb + 1) * 4);
+    s.block_off = (uint32_t*)(p + o); o += up(n_bin_blocks(n) * nb * 4);
     s.ranges = (uint2*)(p + o); o += up(nl * 8);
     s.order = (uint32_t*)(p + o); o += up(nl * 4);
     s.class_bounds = (uint32_t*)(p + o); o += up(8 * 4);
@@ -100,35 +113,22 @@ ProjectState carve_project(void* base, int64_t n, int64_t nl) {
     return s;
 }
 
-// Binning scratch.  Pairs are radix-sorted by list id only (ceil(log2 lists) key bits: 2 onesweep passes) with a 64-bit
-// payload (depth bits << 32 | Gaussian id); the depth order inside every list is then produced by a per-list sort in LDS
-// (list_sort_kernel).  Sorting 64-bit (list, depth) keys globally took 6 passes.
+// Binning scratch: pairs in coarse-bin order (local list id + payload), then the payloads in list order.
 struct BinScratch {
-    uint32_t *keys_in, *keys_out;     // [P] list id
-    uint64_t *vals_in, *vals_out;     // [P] depth bits << 32 | id
-    void* temp;
-    size_t temp_bytes;
+    uint8_t* bkeys;          // [P] list id inside the bin (0..63)
+    uint64_t* bvals;         // [P] depth bits << 32 | id, bin order
+    uint64_t* vals;          // [P] the same, list order (unsorted inside a list)
     int64_t bytes;
 };
-
-size_t bin_temp_bytes(int64_t n_pairs) {
-    size_t c = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, c, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint64_t*)nullptr, (uint64_t*)nullptr,
-                                    (size_t)(n_pairs > 0 ? n_pairs : 1), 0u, 32u, (hipStream_t)0);
-    return c;
-}
 
 BinScratch carve_bin_scratch(void* base, int64_t n_pairs) {
     BinScratch s;
     char* p = (char*)base;
     int64_t o = 0;
     const int64_t np = n_pairs > 0 ? n_pairs : 1;
-    s.keys_in = (uint32_t*)(p + o); o += up(np * 4);
-    s.keys_out = (uint32_t*)(p + o); o += up(np * 4);
-    s.vals_in = (uint64_t*)(p + o); o += up(np * 8);
-    s.vals_out = (uint64_t*)(p + o); o += up(np * 8);
-    s.temp_bytes = bin_temp_bytes(np);
-    s.temp = (void*)(p + o); o += up((int64_t)s.temp_bytes);
+    s.bkeys = (uint8_t*)(p + o); o += up(np);
+    s.bvals = (uint64_t*)(p + o); o += up(np * 8);
+    s.vals = (uint64_t*)(p + o); o += up(np * 8);
     s.bytes = o;
     return s;
 }
@@ -137,7 +137,7 @@ int check_view(const gsplat_view* v) {
     if (!v) return fail(GSPLAT_ERR_BAD_ARG, "view is NULL");
     if (v->H <= 0 || v->W <= 0) return fail(GSPLAT_ERR_BAD_ARG, "image size must be positive");
     if (v->tile != 16) return fail(GSPLAT_ERR_BAD_ARG, "only tile size T=16 is built (the image does not depend on T)");
-    if ((v->W + 15) / 16 > 65535 || (v->H + 15) / 16 > 65535) return fail(GSPLAT_ERR_BAD_ARG, "image too large");
+    if ((v->W + 15) / 16 > 65535 || (v->H + 7) / 8 > 65535 || n_bins(n_lists(v)) > MAX_BINS) return fail(GSPLAT_ERR_BAD_ARG, "image too large");
     return GSPLAT_OK;
 }
 
@@ -211,7 +211,9 @@ __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t n) {
 }
 
 // ---- K0 ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void camera_kernel(const float* __restrict__ c2w, Camera* cam, DevCounts* counts, CountShard* shards) {
+__global__ __launch_bounds__(256) void camera_kernel(const float* __restrict__ c2w, Camera* cam, DevCounts* counts, CountShard* shards,
+                                                     uint32_t* __restrict__ bin_total, int nb) {
+    for (int b = threadIdx.x; b < nb; b += 256) bin_total[b] = 0u;
     if (threadIdx.x < COUNT_SHARDS) {
         CountShard z;
         z.survivors = 0; z.visible = 0; z.max_tiles = 0; z.ref_pairs = 0u; z.bin_pairs = 0u;
@@ -360,7 +362,7 @@ __device__ __forceinline__ void for_each_list(u2 rect, uint32_t nt, int tiles_x,
 // queued behind the copy of the counters so that it runs while the host reads them and sizes the binning buffers.
 template <bool FUSED, bool COLOUR>
 __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const Camera* __restrict__ camp, ViewK vk, Records out,
-                                                     CountShard* shards, uint32_t* __restrict__ wave_pairs) {
+                                                     CountShard* shards) {
     __shared__ ProjectLds s;
     __shared__ float s_dc[FUSED && COLOUR ? 64 * 3 : 4];
     __shared__ float s_rest[FUSED && COLOUR ? 64 * 45 : 4];
@@ -412,7 +414,6 @@ __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const C
         if (mx) atomicMax(&sh->max_tiles, (int)mx);
         if (refp) atomicAdd(&sh->ref_pairs, refp);
         if (binp) atomicAdd(&sh->bin_pairs, binp);
-        wave_pairs[blockIdx.x] = binp;            // scanned by scan_kernel -> where this block's pairs start
     }
 }
 
@@ -442,107 +443,150 @@ __global__ __launch_bounds__(64) void colour_kernel(gsplat_gaussians g, const Ca
     }
 }
 
-// ---- K2: scan --------------------------------------------------------------------------------------
-// One workgroup: exclusive prefix over the per-block (64 Gaussians) pair counts, in place, and the totals of the sharded
-// counters.  Replaces a device-wide scan over all Gaussians (three library kernels) and the counter reduction.
-__global__ __launch_bounds__(1024) void scan_kernel(int nw, uint32_t* __restrict__ wave_off, const CountShard* __restrict__ shards,
-                                                    DevCounts* counts) {
-    constexpr int K = 16;                                    // entries per thread and round, held in registers
-    __shared__ uint32_t wsum[16];
-    __shared__ long long tot[5];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < 5) tot[tid] = 0;
-    __syncthreads();
-    uint32_t carry = 0u;
-    for (int base = 0; base < nw; base += 1024 * K) {
-        const int first = base + tid * K;
-        uint32_t c[K], run = 0u;
+// ---- K2: counter totals ----------------------------------------------------------------------------
+__global__ __launch_bounds__(COUNT_SHARDS) void finish_counts_kernel(const CountShard* __restrict__ shards, DevCounts* counts) {
+    __shared__ unsigned long long part[5][COUNT_SHARDS / 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const CountShard sh = shards[tid];
+    unsigned long long v[4] = {(unsigned long long)sh.survivors, (unsigned long long)sh.visible, (unsigned long long)sh.ref_pairs,
+                               (unsigned long long)sh.bin_pairs};
+    uint32_t mxt = (uint32_t)sh.max_tiles;
+    for (int sft = 32; sft > 0; sft >>= 1) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) c[k] = first + k < nw ? wave_off[first + k] : 0u;
-#pragma unroll
-        for (int k = 0; k < K; ++k) run += c[k];
-        uint32_t incl = run;
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up_ = (uint32_t)__shfl_up((int)incl, d);
-            if (lane >= d) incl += up_;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        uint32_t woff = 0u, total = 0u;
-        for (int k = 0; k < 16; ++k) { const uint32_t v = wsum[k]; if (k < wave) woff += v; total += v; }
-        uint32_t st = carry + woff + incl - run;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            if (first + k < nw) wave_off[first + k] = st;
-            st += c[k];
-        }
-        carry += total;
-        __syncthreads();
+        for (int k = 0; k < 4; ++k) v[k] += (unsigned long long)__shfl_xor((long long)v[k], sft);
+        mxt = max(mxt, (uint32_t)__shfl_xor((int)mxt, sft));
     }
-    if (tid < COUNT_SHARDS) {           // totals of the sharded counters (COUNT_SHARDS <= 1024): wave sums, then 4 x 5 LDS atomics
-        const CountShard sh = shards[tid];
-        unsigned long long v[4] = {(unsigned long long)sh.survivors, (unsigned long long)sh.visible, (unsigned long long)sh.ref_pairs,
-                                   (unsigned long long)sh.bin_pairs};
-        uint32_t mxt = (uint32_t)sh.max_tiles;
-        for (int sft = 32; sft > 0; sft >>= 1) {
+    if (lane == 0) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] += (unsigned long long)__shfl_xor((long long)v[k], sft);
-            mxt = max(mxt, (uint32_t)__shfl_xor((int)mxt, sft));
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) atomicAdd((unsigned long long*)&tot[k], v[k]);
-            atomicMax((unsigned long long*)&tot[4], (unsigned long long)mxt);
-        }
+        for (int k = 0; k < 4; ++k) part[k][tid >> 6] = v[k];
+        part[4][tid >> 6] = mxt;
     }
     __syncthreads();
     if (tid == 0) {
-        counts->n_survivors = (int32_t)tot[0]; counts->n_visible = (int32_t)tot[1]; counts->n_pairs = tot[2];
-        counts->n_binned = tot[3]; counts->max_tiles = (int32_t)tot[4];
+        unsigned long long t[5] = {0, 0, 0, 0, 0};
+        for (int w = 0; w < COUNT_SHARDS / 64; ++w) {
+            for (int k = 0; k < 4; ++k) t[k] += part[k][w];
+            t[4] = max(t[4], part[4][w]);
+        }
+        counts->n_survivors = (int32_t)t[0]; counts->n_visible = (int32_t)t[1]; counts->n_pairs = (int64_t)t[2];
+        counts->n_binned = (int64_t)t[3]; counts->max_tiles = (int32_t)t[4];
     }
 }
 
-// ---- K3: emit --------------------------------------------------------------------------------------
-// F11: key = list id (u32), payload = float_bits(z) << 32 | Gaussian index (u64).  z > 0, so the bit pattern orders
-// like the value; equal depths fall back to the index.  Same 64-Gaussian blocks as project_kernel.
-__global__ __launch_bounds__(64) void emit_pairs_kernel(int64_t n, const float* __restrict__ depth, const u2* __restrict__ rect,
-                                                        const uint32_t* __restrict__ tiles, const uint32_t* __restrict__ wave_off,
-                                                        int tiles_x, uint32_t n_binned, uint32_t* __restrict__ keys,
-                                                        uint64_t* __restrict__ vals) {
-    const int lane = threadIdx.x;
-    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
-    const uint32_t nt = i < n ? tiles[i] : 0u;
-    if (!__any(nt != 0u)) return;
-    uint32_t incl = nt;
+// ---- K3: coarse bins (F11) -----------------------------------------------------------------------------
+// bin_count_kernel: a block of 2048 Gaussians histograms its (list, Gaussian) pairs over the coarse bins in LDS and takes
+// its share of every bin it touches with ONE returning global atomic per bin (device-scope atomics run at ~20 G/s and
+// serialise per address: one per pair was 10x slower than the radix sort this replaces; one per block and bin is noise).
+// Needs no pair buffer, so it is queued with the colour pass behind the counters and runs during the host round trip.
+template <class F>
+__device__ __forceinline__ void for_block_pairs(int64_t n, const u2* __restrict__ rect, const uint32_t* __restrict__ tiles,
+                                                const float* __restrict__ depth, int tiles_x, F f) {
+    const int tid = threadIdx.x, lane = tid & 63;
+#pragma unroll 1
+    for (int k = 0; k < BIN_GAUSS / 256; ++k) {
+        const int64_t i = (int64_t)blockIdx.x * BIN_GAUSS + k * 256 + tid;
+        const uint32_t nt = i < n ? tiles[i] : 0u;
+        u2 r = u2{0u, 0u};
+        uint64_t payload = 0ull;
+        if (nt) {
+            r = rect[i];
+            // z > 0: the float's bit pattern orders like its value; equal depths fall back to the Gaussian index
+            if (depth) payload = ((uint64_t)f2u(depth[i]) << 32) | (uint64_t)(uint32_t)i;
+        }
+        for_each_list(r, nt, tiles_x, lane, payload, 0u, f);
+    }
+}
+
+__global__ __launch_bounds__(256) void bin_count_kernel(int64_t n, const u2* __restrict__ rect, const uint32_t* __restrict__ tiles,
+                                                        int tiles_x, int nb, uint32_t* __restrict__ bin_total,
+                                                        uint32_t* __restrict__ block_off) {
+    __shared__ uint32_t hist[MAX_BINS];
+    const int tid = threadIdx.x;
+    for (int b = tid; b < nb; b += 256) hist[b] = 0u;
+    __syncthreads();
+    for_block_pairs(n, rect, tiles, nullptr, tiles_x, [&](uint32_t l, uint32_t, uint64_t, uint32_t) { atomicAdd(&hist[l >> BIN_SHIFT], 1u); });
+    __syncthreads();
+    for (int b = tid; b < nb; b += 256) {
+        const uint32_t c = hist[b];
+        if (c) block_off[(int64_t)blockIdx.x * nb + b] = atomicAdd(&bin_total[b], c);
+    }
+}
+
+// bin_scatter_kernel: the same enumeration; a pair goes to bin_start[bin] + the block's offset in the bin + its arrival
+// rank inside the block (LDS atomic).  The order inside a bin is arbitrary; the per-list sort by the unique payload makes
+// the final order deterministic.
+__global__ __launch_bounds__(256) void bin_scatter_kernel(int64_t n, const u2* __restrict__ rect, const uint32_t* __restrict__ tiles,
+                                                          const float* __restrict__ depth, int tiles_x, int nb,
+                                                          const uint32_t* __restrict__ bin_total, const uint32_t* __restrict__ block_off,
+                                                          uint32_t* __restrict__ bin_start, uint32_t n_binned,
+                                                          uint8_t* __restrict__ bkeys, uint64_t* __restrict__ bvals) {
+    __shared__ uint32_t cur[MAX_BINS], wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // exclusive prefix of the bin totals: thread t owns a contiguous run of ceil(nb / 256) bins
+    const int per = (nb + 255) / 256, first = tid * per;
+    uint32_t run = 0u;
+    for (int k = 0; k < per; ++k) run += first + k < nb ? bin_total[first + k] : 0u;
+    uint32_t incl = run;
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t up_ = (uint32_t)__shfl_up((int)incl, d);
         if (lane >= d) incl += up_;
     }
-    const uint32_t first = wave_off[blockIdx.x] + incl - nt;
-    u2 r = u2{0u, 0u};
-    uint64_t payload = 0ull;
-    if (nt) {
-        r = rect[i];
-        payload = ((uint64_t)f2u(depth[i]) << 32) | (uint64_t)(uint32_t)i;
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t st = incl - run;
+    for (int k = 0; k < wave; ++k) st += wsum[k];
+    for (int k = 0; k < per; ++k) {
+        const int b = first + k;
+        if (b < nb) {
+            const uint32_t c = bin_total[b];
+            cur[b] = st + block_off[(int64_t)blockIdx.x * nb + b];        // garbage for bins this block never touches: unused
+            if (blockIdx.x == 0) {
+                bin_start[b] = st;
+                if (b == nb - 1) bin_start[nb] = st + c;
+            }
+            st += c;
+        }
     }
-    for_each_list(r, nt, tiles_x, lane, payload, first, [&](uint32_t l, uint32_t k, uint64_t pl, uint32_t at) {
-        const uint32_t pos = at + k;
+    __syncthreads();
+    for_block_pairs(n, rect, tiles, depth, tiles_x, [&](uint32_t l, uint32_t, uint64_t pl, uint32_t) {
+        const uint32_t pos = atomicAdd(&cur[l >> BIN_SHIFT], 1u);
         if (pos < n_binned) {                               // defensive: never write past the caller's buffer
-            keys[pos] = l;
-            vals[pos] = pl;
+            bkeys[pos] = (uint8_t)(l & ((1u << BIN_SHIFT) - 1u));
+            bvals[pos] = pl;
         }
     });
 }
 
-// ---- K5: list ranges and plan ------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void list_ranges_kernel(int64_t n_pairs, const uint32_t* __restrict__ keys, uint2* ranges) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_pairs) return;
-    const uint32_t t = keys[i];
-    if (i == 0 || keys[i - 1] != t) ranges[t].x = (uint32_t)i;
-    if (i == n_pairs - 1 || keys[i + 1] != t) ranges[t].y = (uint32_t)(i + 1);
+// bin_local_kernel: one workgroup per coarse bin splits the bin's pairs into its 64 lists (LDS histogram, scan, LDS
+// cursors) and writes every list's [start, end).
+__global__ __launch_bounds__(1024) void bin_local_kernel(int nl, const uint32_t* __restrict__ bin_start, const uint8_t* __restrict__ bkeys,
+                                                         const uint64_t* __restrict__ bvals, uint32_t n_binned,
+                                                         uint2* __restrict__ ranges, uint64_t* __restrict__ vals) {
+    constexpr int L = 1 << BIN_SHIFT;
+    __shared__ uint32_t cnt[L], cur[L];
+    const int tid = threadIdx.x;
+    const uint32_t s = bin_start[blockIdx.x], e = min(bin_start[blockIdx.x + 1], n_binned);
+    if (tid < L) cnt[tid] = 0u;
+    __syncthreads();
+    for (uint32_t p = s + tid; p < e; p += 1024) atomicAdd(&cnt[bkeys[p]], 1u);
+    __syncthreads();
+    if (tid < L) {                                            // one wave: exclusive scan of the 64 list sizes
+        const uint32_t c = cnt[tid];
+        uint32_t incl = c;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up_ = (uint32_t)__shfl_up((int)incl, d);
+            if (tid >= d) incl += up_;
+        }
+        const uint32_t st = s + incl - c;
+        cur[tid] = st;
+        const int list = blockIdx.x * L + tid;
+        if (list < nl) ranges[list] = uint2{st, st + c};
+    }
+    __syncthreads();
+    for (uint32_t p = s + tid; p < e; p += 1024) vals[atomicAdd(&cur[bkeys[p]], 1u)] = bvals[p];
 }
 
+// ---- K5: plan ----------------------------------------------------------------------------------------
 // Longest-processing-time-first launch order of the lists (1/8-octave buckets of the list length: the raster kernels
 // are tail-bound, a few dense lists take 5x the mean, so they must start first), and the boundaries of the sort size
 // classes inside that order.
@@ -1275,27 +1319,31 @@ int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_vie
     if (!c2w || !project_state) return fail(GSPLAT_ERR_BAD_ARG, "c2w / project_state is NULL");
     hipStream_t st = (hipStream_t)stream_;
     const int64_t n = g->n;
-    const int64_t nl = n_lists(v);
-    if (nl > 0x7fffffffLL) return fail(GSPLAT_ERR_BAD_ARG, "image too large");
+    const int64_t nl = n_lists(v), nb = n_bins(nl);
     ProjectState ps = carve_project(project_state, n > 0 ? n : 1, nl);
     const ViewK vk = make_viewk(*v);
-    hipLaunchKernelGGL(camera_kernel, dim3(1), dim3(256), 0, st, c2w, ps.cam, ps.counts, ps.shards);
+    hipLaunchKernelGGL(camera_kernel, dim3(1), dim3(256), 0, st, c2w, ps.cam, ps.counts, ps.shards, ps.bin_total, (int)nb);
     LAUNCH_CHECK("camera_kernel");
     if (n > 0) {
         Records out{ps.rec, ps.rect, ps.depth, ps.tiles, nullptr, nullptr};
         if (fused)
-            hipLaunchKernelGGL((project_kernel<true, false>), dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, vk, out, ps.shards, ps.wave_off);
+            hipLaunchKernelGGL((project_kernel<true, false>), dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, vk, out, ps.shards);
         else
-            hipLaunchKernelGGL((project_kernel<false, true>), dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, vk, out, ps.shards, ps.wave_off);
+            hipLaunchKernelGGL((project_kernel<false, true>), dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, vk, out, ps.shards);
         LAUNCH_CHECK("project_kernel");
     }
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, (int)blocks64(n), ps.wave_off, ps.shards, ps.counts);
-    LAUNCH_CHECK("scan_kernel");
+    hipLaunchKernelGGL(finish_counts_kernel, dim3(1), dim3(COUNT_SHARDS), 0, st, ps.shards, ps.counts);
+    LAUNCH_CHECK("finish_counts_kernel");
     if (counts_host) HIP_TRY(hipMemcpyAsync(counts_host, ps.counts, sizeof(gsplat_counts), hipMemcpyDeviceToHost, st));
     if (counts_event) HIP_TRY(hipEventRecord((hipEvent_t)counts_event, st));
-    if (n > 0 && fused) {           // runs while the host waits for the counters and sizes the binning buffers
-        hipLaunchKernelGGL(colour_kernel, dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, ps.tiles, ps.rec);
-        LAUNCH_CHECK("colour_kernel");
+    if (n > 0) {                    // these two need no pair buffer: they run while the host waits for the counters
+        hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)n_bin_blocks(n)), dim3(256), 0, st, n, ps.rect, ps.tiles, vk.tiles_x, (int)nb,
+                           ps.bin_total, ps.block_off);
+        LAUNCH_CHECK("bin_count_kernel");
+        if (fused) {
+            hipLaunchKernelGGL(colour_kernel, dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, ps.tiles, ps.rec);
+            LAUNCH_CHECK("colour_kernel");
+        }
     }
     return GSPLAT_OK;
 }
@@ -1308,10 +1356,10 @@ int gsplat_bin(int64_t n, int64_t n_binned, const gsplat_view* v, const void* pr
     if (!project_state || !bin_state) return fail(GSPLAT_ERR_BAD_ARG, "state is NULL");
     hipStream_t st = (hipStream_t)stream_;
     const ViewK vk = make_viewk(*v);
-    const int64_t nl = n_lists(v);
+    const int64_t nl = n_lists(v), nb = n_bins(nl);
     ProjectState ps = carve_project((void*)project_state, n > 0 ? n : 1, nl);
-    HIP_TRY(hipMemsetAsync(ps.ranges, 0, nl * sizeof(uint2), st));
     if (n_binned == 0 || n == 0) {
+        HIP_TRY(hipMemsetAsync(ps.ranges, 0, nl * sizeof(uint2), st));
         hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, (int)nl, ps.ranges, ps.order, ps.class_bounds);
         LAUNCH_CHECK("plan_kernel");
         return GSPLAT_OK;
@@ -1319,22 +1367,16 @@ int gsplat_bin(int64_t n, int64_t n_binned, const gsplat_view* v, const void* pr
     BinScratch sc = carve_bin_scratch(scratch, n_binned);
     if (!scratch || sc.bytes > scratch_bytes) return fail(GSPLAT_ERR_WORKSPACE, "bin scratch too small");
     uint32_t* sorted_ids = (uint32_t*)bin_state;
-    hipLaunchKernelGGL(emit_pairs_kernel, dim3(blocks64(n)), dim3(64), 0, st, n, ps.depth, ps.rect, ps.tiles, ps.wave_off, vk.tiles_x,
-                       (uint32_t)n_binned, sc.keys_in, sc.vals_in);
-    LAUNCH_CHECK("emit_pairs_kernel");
-    // F12 (list part): radix sort on the list-id bits only
-    unsigned list_bits = 1;
-    while ((1LL << list_bits) < nl) ++list_bits;
-    size_t tb = sc.temp_bytes;
-    HIP_TRY(rocprim::radix_sort_pairs(sc.temp, tb, sc.keys_in, sc.keys_out, sc.vals_in, sc.vals_out, (size_t)n_binned, 0u, list_bits,
-                                      st));
-    hipLaunchKernelGGL(list_ranges_kernel, dim3(blocks256(n_binned)), dim3(256), 0, st, n_binned, sc.keys_out, ps.ranges);
-    LAUNCH_CHECK("list_ranges_kernel");
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3((unsigned)n_bin_blocks(n)), dim3(256), 0, st, n, ps.rect, ps.tiles, ps.depth, vk.tiles_x,
+                       (int)nb, ps.bin_total, ps.block_off, ps.bin_start, (uint32_t)n_binned, sc.bkeys, sc.bvals);
+    LAUNCH_CHECK("bin_scatter_kernel");
+    hipLaunchKernelGGL(bin_local_kernel, dim3((unsigned)nb), dim3(1024), 0, st, (int)nl, ps.bin_start, sc.bkeys, sc.bvals,
+                       (uint32_t)n_binned, ps.ranges, sc.vals);
+    LAUNCH_CHECK("bin_local_kernel");
     hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, (int)nl, ps.ranges, ps.order, ps.class_bounds);
     LAUNCH_CHECK("plan_kernel");
-    // F9 + F12 (depth part): per-list sort by (depth, index); one launch per size class, grids bounded by what the class
-    // can hold
-    uint64_t* vals = sc.vals_out;
+    // F9 + F12: per-list sort by (depth, index); one launch per size class, grids bounded by what the class can hold
+    uint64_t* vals = sc.vals;
     const auto cap = [&](int64_t min_len) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(nl, n_binned / min_len)); };
     if (n_binned >= 4096) {
         hipLaunchKernelGGL(huge_sort_kernel, dim3(cap(4096)), dim3(256), 0, st, ps.order, ps.class_bounds, ps.ranges, vals, sorted_ids);

@@ -18,7 +18,7 @@ params, cam = bench.synthetic_scene(cfg)
 dev = torch.device("cuda:0")
 p = {k: v.to(dev).requires_grad_(True) for k, v in params.items()}
 H, W = cam["H"], cam["W"]
-nreg = 2 * ((H + 15) // 16) * ((W + 15) // 16)
+nreg = ((H + 7) // 8) * ((W + 15) // 16)            # one record per half-tile list
 sf = torch.zeros(nreg, 4, dtype=torch.int32, device=dev)
 sb = torch.zeros(nreg, 4, dtype=torch.int32, device=dev)
 lib = abi.lib()
