@@ -53,7 +53,7 @@ SIGNATURES = {
     "gsplat_project_state_bytes": (_I64, [_I64, _PV]),
     "gsplat_project_scratch_bytes": (_I64, [_I64]),
     "gsplat_bin_state_bytes": (_I64, [_I64, _PV]),
-    "gsplat_bin_scratch_bytes": (_I64, [_I64, _I64]),
+    "gsplat_bin_scratch_bytes": (_I64, [_I64, _PV]),
     "gsplat_project": (_INT, [_PG, _VP, _PV, _VP, _VP, _I64, _VP, _VP, _VP]),
     "gsplat_bin": (_INT, [_I64, _I64, _PV, _VP, _VP, _VP, _I64, _VP]),
     "gsplat_rasterize_forward": (_INT, [_I64, _I64, _PV, _VP, _VP, _VP, _VP, _VP]),

@@ -69,6 +69,11 @@ struct alignas(64) CountShard { int32_t survivors, visible, max_tiles; uint32_t 
 constexpr int BIN_SHIFT = 6;                 // 64 lists per coarse bin
 constexpr int BIN_GAUSS = 2048;              // Gaussians per block of bin_count_kernel / bin_scatter_kernel
 constexpr int MAX_BINS = 8192;               // LDS histogram of the two kernels (32 KB): images up to 8192 x 8192 / 128 lists
+constexpr int SPLIT_CHUNK = 4096;            // pairs per block of split_count_kernel / split_scatter_kernel
+// Pair payload (64 bit): float_bits(z) << 32 | list index inside its bin << ID_BITS | Gaussian index.  z > 0, so the
+// bit pattern orders like the value; inside one list the middle field is constant: sorting payloads = (depth, index) order.
+constexpr int ID_BITS = 32 - BIN_SHIFT;      // 26: up to 67 M Gaussians per call
+constexpr uint32_t ID_MASK = (1u << ID_BITS) - 1u;
 
 struct ProjectState {
     Camera* cam;
@@ -81,6 +86,7 @@ struct ProjectState {
     uint32_t* bin_total;     // [bins] pairs per coarse bin
     uint32_t* bin_start;     // [bins + 1] exclusive prefix of bin_total
     uint32_t* block_off;     // [blocks x bins] where a block's pairs start inside a bin
+    uint32_t* list_count;    // [bins x 64] pairs per list (split_count_kernel)
     uint2* ranges;           // [lists] start, end in the pair arrays
     uint32_t* order;         // [lists] launch order: longest list first
     uint32_t* class_bounds;  // [8] boundaries of the sort size classes inside `order`
@@ -106,6 +112,7 @@ ProjectState carve_project(void* base, int64_t n, int64_t nl) {
     s.bin_total = (uint32_t*)(p + o); o += up(nb * 4);
     s.bin_start = (uint32_t*)(p + o); o += up((nb + 1) * 4);
     s.block_off = (uint32_t*)(p + o); o += up(n_bin_blocks(n) * nb * 4);
+    s.list_count = (uint32_t*)(p + o); o += up((nb << BIN_SHIFT) * 4);
     s.ranges = (uint2*)(p + o); o += up(nl * 8);
     s.order = (uint32_t*)(p + o); o += up(nl * 4);
     s.class_bounds = (uint32_t*)(p + o); o += up(8 * 4);
@@ -113,22 +120,25 @@ ProjectState carve_project(void* base, int64_t n, int64_t nl) {
     return s;
 }
 
-// Binning scratch: pairs in coarse-bin order (local list id + payload), then the payloads in list order.
+// Binning scratch: payloads in coarse-bin order, then in list order (unsorted inside a list), and the offsets the
+// chunks of the split kernels drew inside their lists.
 struct BinScratch {
-    uint8_t* bkeys;          // [P] list id inside the bin (0..63)
-    uint64_t* bvals;         // [P] depth bits << 32 | id, bin order
-    uint64_t* vals;          // [P] the same, list order (unsorted inside a list)
+    uint64_t* bvals;         // [P] bin order
+    uint64_t* vals;          // [P] list order
+    uint32_t* seg_off;       // [(chunks + bins) x 64]
     int64_t bytes;
 };
 
-BinScratch carve_bin_scratch(void* base, int64_t n_pairs) {
+inline int64_t n_chunks(int64_t n_pairs) { return (n_pairs + SPLIT_CHUNK - 1) / SPLIT_CHUNK; }
+
+BinScratch carve_bin_scratch(void* base, int64_t n_pairs, int64_t nb) {
     BinScratch s;
     char* p = (char*)base;
     int64_t o = 0;
     const int64_t np = n_pairs > 0 ? n_pairs : 1;
-    s.bkeys = (uint8_t*)(p + o); o += up(np);
     s.bvals = (uint64_t*)(p + o); o += up(np * 8);
     s.vals = (uint64_t*)(p + o); o += up(np * 8);
+    s.seg_off = (uint32_t*)(p + o); o += up((n_chunks(np) + nb) * 64 * 4);
     s.bytes = o;
     return s;
 }
@@ -143,7 +153,7 @@ int check_view(const gsplat_view* v) {
 
 int check_gaussians(const gsplat_gaussians* g, bool* fused) {
     if (!g) return fail(GSPLAT_ERR_BAD_ARG, "gaussians is NULL");
-    if (g->n < 0 || g->n > 0x7fffffffLL) return fail(GSPLAT_ERR_BAD_ARG, "n out of range");
+    if (g->n < 0 || g->n > (int64_t)ID_MASK + 1) return fail(GSPLAT_ERR_BAD_ARG, "n out of range (at most 2^26 Gaussians per call)");
     const bool f = g->scale_raw || g->q_raw || g->f_dc || g->f_rest;
     const bool u = g->color || g->sigma;
     if (f == u) return fail(GSPLAT_ERR_BAD_ARG, "give either (color, sigma) or (scale_raw, q_raw, f_dc, f_rest)");
@@ -482,26 +492,39 @@ template <class F>
 __device__ __forceinline__ void for_block_pairs(int64_t n, const u2* __restrict__ rect, const uint32_t* __restrict__ tiles,
                                                 const float* __restrict__ depth, int tiles_x, F f) {
     const int tid = threadIdx.x, lane = tid & 63;
-#pragma unroll 1
-    for (int k = 0; k < BIN_GAUSS / 256; ++k) {
+    constexpr int K = BIN_GAUSS / 256;
+    uint32_t nt[K];
+    u2 r[K];
+    uint64_t payload[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {            // all loads of the thread's 8 Gaussians in flight together
         const int64_t i = (int64_t)blockIdx.x * BIN_GAUSS + k * 256 + tid;
-        const uint32_t nt = i < n ? tiles[i] : 0u;
-        u2 r = u2{0u, 0u};
-        uint64_t payload = 0ull;
-        if (nt) {
-            r = rect[i];
-            // z > 0: the float's bit pattern orders like its value; equal depths fall back to the Gaussian index
-            if (depth) payload = ((uint64_t)f2u(depth[i]) << 32) | (uint64_t)(uint32_t)i;
-        }
-        for_each_list(r, nt, tiles_x, lane, payload, 0u, f);
+        nt[k] = i < n ? tiles[i] : 0u;
     }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int64_t i = (int64_t)blockIdx.x * BIN_GAUSS + k * 256 + tid;
+        r[k] = u2{0u, 0u};
+        payload[k] = 0ull;
+        if (nt[k]) {
+            r[k] = rect[i];
+            if (depth) payload[k] = ((uint64_t)f2u(depth[i]) << 32) | (uint64_t)(uint32_t)i;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) for_each_list(r[k], nt[k], tiles_x, lane, payload[k], 0u, f);
 }
 
 __global__ __launch_bounds__(256) void bin_count_kernel(int64_t n, const u2* __restrict__ rect, const uint32_t* __restrict__ tiles,
                                                         int tiles_x, int nb, uint32_t* __restrict__ bin_total,
-                                                        uint32_t* __restrict__ block_off) {
+                                                        uint32_t* __restrict__ block_off, uint32_t* __restrict__ list_count,
+                                                        uint2* __restrict__ ranges, int nl) {
     __shared__ uint32_t hist[MAX_BINS];
     const int tid = threadIdx.x;
+    for (int l = blockIdx.x * 256 + tid; l < (nb << BIN_SHIFT); l += gridDim.x * 256) {     // for the split kernels
+        list_count[l] = 0u;
+        if (l < nl) ranges[l] = uint2{0u, 0u};
+    }
     for (int b = tid; b < nb; b += 256) hist[b] = 0u;
     __syncthreads();
     for_block_pairs(n, rect, tiles, nullptr, tiles_x, [&](uint32_t l, uint32_t, uint64_t, uint32_t) { atomicAdd(&hist[l >> BIN_SHIFT], 1u); });
@@ -519,7 +542,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(int64_t n, const u2* _
                                                           const float* __restrict__ depth, int tiles_x, int nb,
                                                           const uint32_t* __restrict__ bin_total, const uint32_t* __restrict__ block_off,
                                                           uint32_t* __restrict__ bin_start, uint32_t n_binned,
-                                                          uint8_t* __restrict__ bkeys, uint64_t* __restrict__ bvals) {
+                                                          uint64_t* __restrict__ bvals) {
     __shared__ uint32_t cur[MAX_BINS], wsum[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // exclusive prefix of the bin totals: thread t owns a contiguous run of ceil(nb / 256) bins
@@ -550,40 +573,91 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(int64_t n, const u2* _
     __syncthreads();
     for_block_pairs(n, rect, tiles, depth, tiles_x, [&](uint32_t l, uint32_t, uint64_t pl, uint32_t) {
         const uint32_t pos = atomicAdd(&cur[l >> BIN_SHIFT], 1u);
-        if (pos < n_binned) {                               // defensive: never write past the caller's buffer
-            bkeys[pos] = (uint8_t)(l & ((1u << BIN_SHIFT) - 1u));
-            bvals[pos] = pl;
-        }
+        if (pos < n_binned)                                 // defensive: never write past the caller's buffer
+            bvals[pos] = pl | ((uint64_t)(l & ((1u << BIN_SHIFT) - 1u)) << ID_BITS);
     });
 }
 
-// bin_local_kernel: one workgroup per coarse bin splits the bin's pairs into its 64 lists (LDS histogram, scan, LDS
-// cursors) and writes every list's [start, end).
-__global__ __launch_bounds__(1024) void bin_local_kernel(int nl, const uint32_t* __restrict__ bin_start, const uint8_t* __restrict__ bkeys,
-                                                         const uint64_t* __restrict__ bvals, uint32_t n_binned,
-                                                         uint2* __restrict__ ranges, uint64_t* __restrict__ vals) {
-    constexpr int L = 1 << BIN_SHIFT;
-    __shared__ uint32_t cnt[L], cur[L];
-    const int tid = threadIdx.x;
-    const uint32_t s = bin_start[blockIdx.x], e = min(bin_start[blockIdx.x + 1], n_binned);
-    if (tid < L) cnt[tid] = 0u;
-    __syncthreads();
-    for (uint32_t p = s + tid; p < e; p += 1024) atomicAdd(&cnt[bkeys[p]], 1u);
-    __syncthreads();
-    if (tid < L) {                                            // one wave: exclusive scan of the 64 list sizes
-        const uint32_t c = cnt[tid];
-        uint32_t incl = c;
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up_ = (uint32_t)__shfl_up((int)incl, d);
-            if (tid >= d) incl += up_;
-        }
-        const uint32_t st = s + incl - c;
-        cur[tid] = st;
-        const int list = blockIdx.x * L + tid;
-        if (list < nl) ranges[list] = uint2{st, st + c};
+// split_count_kernel / split_scatter_kernel: every bin is split into its 64 lists.  Work is cut into chunks of 4096 pairs
+// of the bin-ordered array (a dense bin of 60 K pairs is shared by 15 workgroups; one workgroup per bin was tail-bound);
+// a chunk that crosses bin boundaries handles one segment per bin.  Count: LDS histogram of the segment over the bin's 64
+// lists, one returning global atomic per list -> the segment's offset inside each list.  Scatter: list start = bin
+// start + prefix of the bin's final list counts; a pair goes to list start + segment offset + arrival rank (LDS atomic).
+// The segment that begins a bin also writes the [start, end) of the bin's lists.  Segment id = chunk + bin (unique: from
+// one segment to the next at least one of the two grows).
+__device__ __forceinline__ int bin_of_pair(const uint32_t* __restrict__ bin_start, int nb, uint32_t p) {
+    int lo = 0, hi = nb;                       // last b in [0, nb) with bin_start[b] <= p
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (bin_start[mid] <= p) lo = mid; else hi = mid;
     }
-    __syncthreads();
-    for (uint32_t p = s + tid; p < e; p += 1024) vals[atomicAdd(&cur[bkeys[p]], 1u)] = bvals[p];
+    return lo;
+}
+
+__device__ __forceinline__ uint32_t local_list(uint64_t v) { return (uint32_t)(v >> ID_BITS) & ((1u << BIN_SHIFT) - 1u); }
+
+__global__ __launch_bounds__(256) void split_count_kernel(int nb, const uint32_t* __restrict__ bin_start, const uint64_t* __restrict__ bvals,
+                                                          uint32_t n_binned, uint32_t* __restrict__ list_count,
+                                                          uint32_t* __restrict__ seg_off) {
+    constexpr int L = 1 << BIN_SHIFT, U = SPLIT_CHUNK / 256;
+    __shared__ uint32_t cnt[L];
+    const int tid = threadIdx.x;
+    const uint32_t c0 = blockIdx.x * (uint32_t)SPLIT_CHUNK, c1 = min(c0 + (uint32_t)SPLIT_CHUNK, n_binned);
+    for (int b = bin_of_pair(bin_start, nb, c0); b < nb && bin_start[b] < c1; ++b) {
+        const uint32_t s = max(c0, bin_start[b]), e = min(c1, bin_start[b + 1]);
+        if (s >= e) continue;                                  // empty bin (uniform)
+        if (tid < L) cnt[tid] = 0u;
+        __syncthreads();
+        uint32_t k[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) k[u] = s + u * 256 + tid < e ? local_list(bvals[s + u * 256 + tid]) : 0xFFFFFFFFu;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (k[u] != 0xFFFFFFFFu) atomicAdd(&cnt[k[u]], 1u);
+        __syncthreads();
+        if (tid < L) {
+            const uint32_t c = cnt[tid];
+            if (c) seg_off[((int64_t)blockIdx.x + b) * L + tid] = atomicAdd(&list_count[b * L + tid], c);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void split_scatter_kernel(int nl, int nb, const uint32_t* __restrict__ bin_start,
+                                                            const uint64_t* __restrict__ bvals, uint32_t n_binned,
+                                                            const uint32_t* __restrict__ list_count, const uint32_t* __restrict__ seg_off,
+                                                            uint2* __restrict__ ranges, uint64_t* __restrict__ vals) {
+    constexpr int L = 1 << BIN_SHIFT, U = SPLIT_CHUNK / 256;
+    __shared__ uint32_t cur[L];
+    const int tid = threadIdx.x;
+    const uint32_t c0 = blockIdx.x * (uint32_t)SPLIT_CHUNK, c1 = min(c0 + (uint32_t)SPLIT_CHUNK, n_binned);
+    for (int b = bin_of_pair(bin_start, nb, c0); b < nb && bin_start[b] < c1; ++b) {
+        const uint32_t bs = bin_start[b], s = max(c0, bs), e = min(c1, bin_start[b + 1]);
+        if (s >= e) continue;
+        if (tid < L) {                                          // one wave: exclusive scan of the bin's 64 list sizes
+            const uint32_t c = list_count[b * L + tid];
+            uint32_t incl = c;
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up_ = (uint32_t)__shfl_up((int)incl, d);
+                if (tid >= d) incl += up_;
+            }
+            const uint32_t st = bs + incl - c;
+            cur[tid] = st + seg_off[((int64_t)blockIdx.x + b) * L + tid];      // garbage where the segment has no pair: unused
+            const int list = b * L + tid;
+            if (s == bs && list < nl) ranges[list] = uint2{st, st + c};
+        }
+        __syncthreads();
+        uint64_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = s + u * 256 + tid < e ? bvals[s + u * 256 + tid] : ~0ull;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (s + u * 256 + tid < e) {
+                const uint32_t pos = atomicAdd(&cur[local_list(v[u])], 1u);
+                if (pos < n_binned) vals[pos] = v[u];
+            }
+        __syncthreads();
+    }
 }
 
 // ---- K5: plan ----------------------------------------------------------------------------------------
@@ -753,7 +827,7 @@ __global__ __launch_bounds__(T) void list_sort_kernel(const uint32_t* __restrict
             const uint64_t a = sk[i], b = sk[l];
             if (a > b) { sk[i] = b; sk[l] = a; }
         });
-        for (uint32_t i = tid; i < n; i += T) out[i] = (uint32_t)sk[i];
+        for (uint32_t i = tid; i < n; i += T) out[i] = (uint32_t)sk[i] & ID_MASK;
         return;
     }
 #pragma unroll
@@ -776,7 +850,7 @@ __global__ __launch_bounds__(T) void list_sort_kernel(const uint32_t* __restrict
             const uint32_t s = b ? cnt[PADC(b - 1u)] : 0u, en = cnt[PADC(b)];
             uint32_t r = s;
             for (uint32_t q = s; q < en; ++q) r += sk[q] < k ? 1u : 0u;
-            out[r] = (uint32_t)k;
+            out[r] = (uint32_t)k & ID_MASK;
         }
     }
 #undef PADC
@@ -796,7 +870,7 @@ __global__ __launch_bounds__(256) void huge_sort_kernel(const uint32_t* __restri
         const uint64_t a = g[i], b = g[l];
         if (a > b) { g[i] = b; g[l] = a; }
     });
-    for (uint32_t i = tid; i < n; i += 256) sorted_ids[rg.x + i] = (uint32_t)g[i];
+    for (uint32_t i = tid; i < n; i += 256) sorted_ids[rg.x + i] = (uint32_t)g[i] & ID_MASK;
 }
 
 // ---- K6 / K7: rasterizer -----------------------------------------------------------------------------
@@ -1304,9 +1378,9 @@ int64_t gsplat_bin_state_bytes(int64_t n_binned, const gsplat_view* v) {
     return up((n_binned > 0 ? n_binned : 1) * 4);                                   // sorted ids
 }
 
-int64_t gsplat_bin_scratch_bytes(int64_t n, int64_t n_binned) {
-    (void)n;
-    return carve_bin_scratch(nullptr, n_binned).bytes;
+int64_t gsplat_bin_scratch_bytes(int64_t n_binned, const gsplat_view* v) {
+    if (!v) return -1;
+    return carve_bin_scratch(nullptr, n_binned, n_bins(n_lists(v))).bytes;
 }
 
 int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, void* project_state, void* scratch,
@@ -1338,7 +1412,7 @@ int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_vie
     if (counts_event) HIP_TRY(hipEventRecord((hipEvent_t)counts_event, st));
     if (n > 0) {                    // these two need no pair buffer: they run while the host waits for the counters
         hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)n_bin_blocks(n)), dim3(256), 0, st, n, ps.rect, ps.tiles, vk.tiles_x, (int)nb,
-                           ps.bin_total, ps.block_off);
+                           ps.bin_total, ps.block_off, ps.list_count, ps.ranges, (int)nl);
         LAUNCH_CHECK("bin_count_kernel");
         if (fused) {
             hipLaunchKernelGGL(colour_kernel, dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, ps.tiles, ps.rec);
@@ -1364,15 +1438,18 @@ int gsplat_bin(int64_t n, int64_t n_binned, const gsplat_view* v, const void* pr
         LAUNCH_CHECK("plan_kernel");
         return GSPLAT_OK;
     }
-    BinScratch sc = carve_bin_scratch(scratch, n_binned);
+    BinScratch sc = carve_bin_scratch(scratch, n_binned, nb);
     if (!scratch || sc.bytes > scratch_bytes) return fail(GSPLAT_ERR_WORKSPACE, "bin scratch too small");
     uint32_t* sorted_ids = (uint32_t*)bin_state;
     hipLaunchKernelGGL(bin_scatter_kernel, dim3((unsigned)n_bin_blocks(n)), dim3(256), 0, st, n, ps.rect, ps.tiles, ps.depth, vk.tiles_x,
-                       (int)nb, ps.bin_total, ps.block_off, ps.bin_start, (uint32_t)n_binned, sc.bkeys, sc.bvals);
+                       (int)nb, ps.bin_total, ps.block_off, ps.bin_start, (uint32_t)n_binned, sc.bvals);
     LAUNCH_CHECK("bin_scatter_kernel");
-    hipLaunchKernelGGL(bin_local_kernel, dim3((unsigned)nb), dim3(1024), 0, st, (int)nl, ps.bin_start, sc.bkeys, sc.bvals,
-                       (uint32_t)n_binned, ps.ranges, sc.vals);
-    LAUNCH_CHECK("bin_local_kernel");
+    hipLaunchKernelGGL(split_count_kernel, dim3((unsigned)n_chunks(n_binned)), dim3(256), 0, st, (int)nb, ps.bin_start, sc.bvals,
+                       (uint32_t)n_binned, ps.list_count, sc.seg_off);
+    LAUNCH_CHECK("split_count_kernel");
+    hipLaunchKernelGGL(split_scatter_kernel, dim3((unsigned)n_chunks(n_binned)), dim3(256), 0, st, (int)nl, (int)nb, ps.bin_start, sc.bvals,
+                       (uint32_t)n_binned, ps.list_count, sc.seg_off, ps.ranges, sc.vals);
+    LAUNCH_CHECK("split_scatter_kernel");
     hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, (int)nl, ps.ranges, ps.order, ps.class_bounds);
     LAUNCH_CHECK("plan_kernel");
     // F9 + F12: per-list sort by (depth, index); one launch per size class, grids bounded by what the class can hold

@@ -187,7 +187,7 @@ def _forward_impl(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad):
             return image.zero_(), fr, counts
         fr.n_pairs = int(counts.n_binned)            # pairs actually binned (half-tile lists); counts.n_pairs = the reference's P
         fr.bin_state = torch.empty(lib.gsplat_bin_state_bytes(fr.n_pairs, C.byref(view)), dtype=torch.uint8, device=dev)
-        sbytes = lib.gsplat_bin_scratch_bytes(n, fr.n_pairs)
+        sbytes = lib.gsplat_bin_scratch_bytes(fr.n_pairs, C.byref(view))
         scratch = _ws.get_scratch(dev, sbytes)
         with _stage("bin"):
             _abi.check(lib.gsplat_bin(n, fr.n_pairs, C.byref(view), _p(fr.proj_state), _p(fr.bin_state), _p(scratch),

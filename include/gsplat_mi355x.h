@@ -111,7 +111,7 @@ int gsplat_classify_counts(const gsplat_counts* counts_host);
 int64_t gsplat_project_state_bytes(int64_t n, const gsplat_view* v);    /* kept until the backward pass */
 int64_t gsplat_project_scratch_bytes(int64_t n);                        /* free after gsplat_project    */
 int64_t gsplat_bin_state_bytes(int64_t n_binned, const gsplat_view* v); /* kept until the backward pass */
-int64_t gsplat_bin_scratch_bytes(int64_t n, int64_t n_binned);          /* free after gsplat_bin        */
+int64_t gsplat_bin_scratch_bytes(int64_t n_binned, const gsplat_view* v); /* free after gsplat_bin      */
 
 /* ---- forward ----------------------------------------------------------------------------------- */
 /* F1-F8, F10, F13 (+F2, F3 when fused): per-Gaussian projection, culls, EWA covariance, eigen clamp,
