@@ -677,14 +677,22 @@ __device__ __forceinline__ uint32_t class_first_bucket(int c) { return c == 0 ? 
 // ascending flat index = descending bucket).
 __global__ __launch_bounds__(1024) void plan_kernel(int nl, const uint2* __restrict__ ranges, uint32_t* __restrict__ order,
                                                     uint32_t* __restrict__ class_bounds) {
-    constexpr int SUB = 16, NF = 256 * SUB;
+    constexpr int SUB = 16, NF = 256 * SUB, K = 16;          // K lists per thread and round, held in registers
     __shared__ uint32_t cnt[NF], wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = tid & (SUB - 1);
     for (int f = tid; f < NF; f += 1024) cnt[f] = 0u;
     __syncthreads();
-    for (int i = tid; i < nl; i += 1024) {
-        const uint2 rg = ranges[i];
-        atomicAdd(&cnt[(255u - work_bucket(rg.y - rg.x)) * SUB + sub], 1u);
+    const bool one_round = nl <= 1024 * K;
+    uint32_t flat[K];                                          // counter index of list (round base + k * 1024 + tid), or ~0
+    for (int base = 0; base < nl; base += 1024 * K) {
+        uint2 rg[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) rg[k] = base + k * 1024 + tid < nl ? ranges[base + k * 1024 + tid] : uint2{0u, 0u};
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            flat[k] = base + k * 1024 + tid < nl ? (255u - work_bucket(rg[k].y - rg[k].x)) * SUB + sub : 0xFFFFFFFFu;
+            if (flat[k] != 0xFFFFFFFFu) atomicAdd(&cnt[flat[k]], 1u);
+        }
     }
     __syncthreads();
     // exclusive prefix over the NF counters: thread t owns 4 consecutive ones
@@ -706,9 +714,18 @@ __global__ __launch_bounds__(1024) void plan_kernel(int nl, const uint2* __restr
     // lists in buckets >= first bucket of a class = prefix at the first sub-counter of the bucket below it
     if (tid < SORT_CLASSES) class_bounds[tid] = cnt[(256u - class_first_bucket(tid)) * SUB];
     __syncthreads();
-    for (int i = tid; i < nl; i += 1024) {
-        const uint2 rg = ranges[i];
-        order[atomicAdd(&cnt[(255u - work_bucket(rg.y - rg.x)) * SUB + sub], 1u)] = (uint32_t)i;
+    for (int base = 0; base < nl; base += 1024 * K) {
+        if (!one_round) {                                      // more than 16384 lists: recompute the counter indices
+            uint2 rg[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) rg[k] = base + k * 1024 + tid < nl ? ranges[base + k * 1024 + tid] : uint2{0u, 0u};
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                flat[k] = base + k * 1024 + tid < nl ? (255u - work_bucket(rg[k].y - rg[k].x)) * SUB + sub : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (flat[k] != 0xFFFFFFFFu) order[atomicAdd(&cnt[flat[k]], 1u)] = (uint32_t)(base + k * 1024 + tid);
     }
 }
 

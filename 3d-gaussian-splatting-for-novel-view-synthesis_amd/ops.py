@@ -90,8 +90,9 @@ class StageTimer:
     """Optional per-stage timing with HIP events recorded on the stream the kernels are launched on (torch's current
     stream).  bench.py installs one with `set_stage_timer`; when none is installed the hooks cost nothing."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.events = []          # (stage, start_event, end_event)
+        self.only = set(only) if only else None      # restrict to these stages (every event pair costs ~10 us of stream time)
 
     def totals_ms(self):
         """stage -> (launches, total milliseconds); call after a device synchronise."""
@@ -120,12 +121,13 @@ class _stage:
         self.name = name
 
     def __enter__(self):
-        if _timer is not None:
+        self.a = None
+        if _timer is not None and (_timer.only is None or self.name in _timer.only):
             self.a = torch.cuda.Event(enable_timing=True)
             self.a.record()
 
     def __exit__(self, *exc):
-        if _timer is not None:
+        if self.a is not None and _timer is not None:
             b = torch.cuda.Event(enable_timing=True)
             b.record()
             _timer.events.append((self.name, self.a, b))
