@@ -18,6 +18,7 @@ struct u2 { uint32_t x, y; };
 //   rec[i] = { (u, v, A11, A12), (A22, opacity, ex, ey), (r, g, b, depth z), (unused) }
 //   rect[i] = (bx0 | by0 << 16, bx1 | by1 << 16)   inclusive rectangle of half-tile lists (16 x 8 pixels each) binned
 //   depth[i] = z                                   tiles[i] = lists touched (0 = contributes to no pixel)
+//   mask[i]: bit k = the ellipse {q <= chi} touches list k of the rectangle (row-major; all ones for rectangles > 32 lists)
 //   ref_rect[i] (host check only) = the reference's own tile rectangle (F10), T x T tiles
 // (ex, ey) are the half-extents of {q <= chi_square_clip}: the rasterizer culls with them at staging time.
 struct alignas(64) Rec64 { f4 r0, r1, r2, pad; };
@@ -27,6 +28,7 @@ struct Records {
     u2* rect;
     float* depth;
     uint32_t* tiles;
+    uint32_t* mask;
     u2* ref_rect;          // nullable
     uint32_t* ref_tiles;   // nullable
 };
@@ -72,6 +74,7 @@ struct RecOut {             // what K1 stores for one Gaussian
     f4 r0, r1, r2;
     u2 rect;                // binned half-tile lists
     uint32_t tiles;         // number of lists
+    uint32_t mask;          // which lists of the rectangle (see Records)
     u2 ref_rect;            // the reference's tile rectangle (F10)
     uint32_t ref_tiles;     // its tile count: the reference's (tile, Gaussian) pairs (F11)
     int vis;
@@ -102,6 +105,7 @@ GS_HD RecOut project_finish(const GaussIn& in, const Proj& o, bool fused, Coef c
     RecOut r;
     r.vis = o.vis;
     r.tiles = 0;
+    r.mask = 0u;
     r.r0 = r.r1 = r.r2 = f4{0.f, 0.f, 0.f, 0.f};
     r.rect = u2{0u, 0u};
     r.ref_rect = u2{0u, 0u};
@@ -119,7 +123,13 @@ GS_HD RecOut project_finish(const GaussIn& in, const Proj& o, bool fused, Coef c
         }
         r.ref_tiles = (uint32_t)((o.tx1 - o.tx0 + 1) * (o.ty1 - o.ty0 + 1));
         r.ref_rect = u2{(uint32_t)o.tx0 | ((uint32_t)o.ty0 << 16), (uint32_t)o.tx1 | ((uint32_t)o.ty1 << 16)};
-        if (o.bx1 >= o.bx0 && o.by1 >= o.by0) r.tiles = (uint32_t)((o.bx1 - o.bx0 + 1) * (o.by1 - o.by0 + 1));
+        if (o.bx1 >= o.bx0 && o.by1 >= o.by0) {
+            const uint32_t area = (uint32_t)((o.bx1 - o.bx0 + 1) * (o.by1 - o.by0 + 1));
+            r.mask = o.bmask;
+            uint32_t bits = 0u;
+            for (uint32_t m = r.mask; m; m &= m - 1u) ++bits;
+            r.tiles = area > 32u ? area : bits;
+        }
         r.r0 = f4{o.u, o.v, o.A11, o.A12};
         r.r1 = f4{o.A22, o.opacity, o.ex, o.ey};
         r.r2 = f4{rgb[0], rgb[1], rgb[2], o.z};
@@ -191,7 +201,7 @@ GS_HD int project_one(int64_t i, const gsplat_gaussians& g, bool fused, Coef coe
     const RecOut r = project_core(load_gauss_global(i, g, fused), fused, coef, cam, vk);
     if (r.vis == VIS_OK) {
         out.rec[i].r0 = r.r0; out.rec[i].r1 = r.r1; out.rec[i].r2 = r.r2;
-        out.rect[i] = r.rect; out.depth[i] = r.r2.w;
+        out.rect[i] = r.rect; out.depth[i] = r.r2.w; out.mask[i] = r.mask;
         if (out.ref_rect) out.ref_rect[i] = r.ref_rect;
     }
     out.tiles[i] = r.tiles;

@@ -223,14 +223,51 @@ struct Proj {
     float opacity;
     int tx0, ty0, tx1, ty1;       // inclusive tile rectangle of the reference (F10/F11: square 2.5-sigma AABB, T x T tiles)
     int bx0, by0, bx1, by1;       // inclusive rectangle actually binned: tight box, T x T/2 half tiles (empty: bx1 < bx0)
+    uint32_t bmask;               // which lists of that rectangle the ellipse can touch (binned_mask)
     int vis;                      // VIS_*
 };
+
+// Does the region {q <= chi} of a projected Gaussian touch the pixel rectangle [x0, x1] x [y0, y1] (pixel centres,
+// inclusive)?  q is convex: if the centre is outside the rectangle the minimum lies on one of the four edges, where it is
+// a clamped 1-D quadratic.  Conservative (a relative 1e-3 margin on chi dwarfs the fp32 differences with the
+// rasterizer's own evaluation of q), so a "no" means alpha = 0 on every pixel of the rectangle.
+GS_HD bool ellipse_touches_rect(const Proj& o, float chi, float x0, float y0, float x1, float y1) {
+    const float dx0 = x0 - o.u, dx1 = x1 - o.u, dy0 = y0 - o.v, dy1 = y1 - o.v;
+    if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;
+    if (!(o.A11 > 0.f && o.A22 > 0.f)) return true;
+    float best = 3.0e38f;
+    const float xs[2] = {dx0, dx1}, ys[2] = {dy0, dy1};
+    for (int k = 0; k < 2; ++k) {
+        const float X = xs[k], t = clampf_(-o.A12 * X / o.A22, dy0, dy1);
+        best = fminf(best, o.A11 * X * X + 2.f * o.A12 * X * t + o.A22 * t * t);
+        const float Y = ys[k], s_ = clampf_(-o.A12 * Y / o.A11, dx0, dx1);
+        best = fminf(best, o.A11 * s_ * s_ + 2.f * o.A12 * s_ * Y + o.A22 * Y * Y);
+    }
+    return !(best > chi * 1.001f + 1e-4f);          // NaN -> true
+}
+
+// Bit k (row-major inside the binned rectangle) = the Gaussian can touch list k.  Rectangles of more than 32 lists are
+// not refined (all ones).
+GS_HD uint32_t binned_mask(const Proj& o, const ViewK& vk) {
+    if (o.bx1 < o.bx0 || o.by1 < o.by0) return 0u;
+    const int w = o.bx1 - o.bx0 + 1, h = o.by1 - o.by0 + 1;
+    if (w * h > 32) return 0xFFFFFFFFu;
+    const int half = vk.tile / 2;
+    uint32_t m = 0u;
+    int k = 0;
+    for (int y = o.by0; y <= o.by1; ++y)
+        for (int x = o.bx0; x <= o.bx1; ++x, ++k)
+            if (ellipse_touches_rect(o, vk.chi_clip, (float)(x * vk.tile), (float)(y * half), (float)(x * vk.tile + vk.tile - 1),
+                                     (float)(y * half + half - 1)))
+                m |= 1u << k;
+    return m;
+}
 
 GS_HD void project_gaussian(const float p[3], const float S[6], float o_raw, const Camera& cam, const ViewK& vk, Proj& o,
                             ProjMid& m) {
     o.vis = VIS_CULLED;
     o.tx0 = o.ty0 = 0; o.tx1 = o.ty1 = -1;
-    o.bx0 = o.by0 = 0; o.bx1 = o.by1 = -1;
+    o.bx0 = o.by0 = 0; o.bx1 = o.by1 = -1; o.bmask = 0u;
     // F4 opacity prefilter
     m.sg = sigmoidf_(o_raw);
     o.opacity = clampf_(m.sg, 0.f, 0.999f);
@@ -338,6 +375,7 @@ GS_HD void project_gaussian(const float p[3], const float S[6], float o_raw, con
             o.bx1 = (int)clampf_(hi_u, 0.f, wm) / vk.tile;
             o.by0 = (int)clampf_(lo_v, 0.f, hm) / half;
             o.by1 = (int)clampf_(hi_v, 0.f, hm) / half;
+            o.bmask = binned_mask(o, vk);
         }
     }
 }

@@ -83,6 +83,7 @@ struct ProjectState {
     u2* rect;                // per Gaussian: inclusive rectangle of lists
     float* depth;
     uint32_t* tiles;         // per Gaussian: number of lists (0 = contributes nowhere)
+    uint32_t* mask;          // per Gaussian: which lists of the rectangle (ellipse / list test; all ones above 32 lists)
     uint32_t* bin_total;     // [bins] pairs per coarse bin
     uint32_t* bin_start;     // [bins + 1] exclusive prefix of bin_total
     uint32_t* block_off;     // [blocks x bins] where a block's pairs start inside a bin
@@ -109,6 +110,7 @@ ProjectState carve_project(void* base, int64_t n, int64_t nl) {
     s.rect = (u2*)(p + o); o += up(n * 8);
     s.depth = (float*)(p + o); o += up(n * 4);
     s.tiles = (uint32_t*)(p + o); o += up(n * 4);
+    s.mask = (uint32_t*)(p + o); o += up(n * 4);
     s.bin_total = (uint32_t*)(p + o); o += up(nb * 4);
     s.bin_start = (uint32_t*)(p + o); o += up((nb + 1) * 4);
     s.block_off = (uint32_t*)(p + o); o += up(n_bin_blocks(n) * nb * 4);
@@ -344,17 +346,19 @@ __device__ __forceinline__ void stage_geometry(ProjectLds& s, const gsplat_gauss
     }
 }
 
-// Calls f(list, ordinal, a, b) for every half-tile list of a Gaussian's rectangle (row-major ordinal 0 .. nt - 1; a, b =
-// the owning lane's values).  Small rectangles: each lane walks its own; rectangles of more than 32 lists (huge
-// Gaussians: up to 32 x 64 lists) are walked by the whole wave, one after the other.  Call with all 64 lanes active.
+// Calls f(list, ordinal, a, b) for every half-tile list of a Gaussian's rectangle whose mask bit is set (row-major;
+// ordinal 0 .. nt - 1 counts the calls; a, b = the owning lane's values).  Rectangles of up to 32 lists: each lane walks
+// its own; larger ones (huge Gaussians: up to 32 x 64 lists; never masked) are walked by the whole wave, one after the
+// other.  Call with all 64 lanes active.
 template <class F>
-__device__ __forceinline__ void for_each_list(u2 rect, uint32_t nt, int tiles_x, int lane, uint64_t a, uint32_t b, F f) {
+__device__ __forceinline__ void for_each_list(u2 rect, uint32_t nt, uint32_t mask, int tiles_x, int lane, uint64_t a, uint32_t b, F f) {
     const int x0 = rect.x & 0xFFFF, y0 = rect.x >> 16, x1 = rect.y & 0xFFFF, y1 = rect.y >> 16;
     const bool big = nt > 32u;
     if (nt && !big) {
-        uint32_t k = 0;
+        uint32_t k = 0, m = mask;
         for (int y = y0; y <= y1; ++y)
-            for (int x = x0; x <= x1; ++x) f((uint32_t)(y * tiles_x + x), k++, a, b);
+            for (int x = x0; x <= x1; ++x, m >>= 1)
+                if (m & 1u) f((uint32_t)(y * tiles_x + x), k++, a, b);
     }
     unsigned long long m = __ballot(big);
     while (m) {
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const C
         o = project_geometry(in, FUSED, cam, vk);
     }
     RecOut r;
-    r.vis = o.vis; r.tiles = 0; r.ref_tiles = 0; r.rect = u2{0u, 0u}; r.ref_rect = u2{0u, 0u};
+    r.vis = o.vis; r.tiles = 0; r.mask = 0u; r.ref_tiles = 0; r.rect = u2{0u, 0u}; r.ref_rect = u2{0u, 0u};
     if (FUSED) {
         if (o.vis == VIS_OK) r = project_finish(in, o, true, ShCoefLds{s_dc + lane * 3, s_rest + lane * 45}, cam, COLOUR);
     } else if (o.vis == VIS_OK) {
@@ -406,6 +410,7 @@ __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const C
             out.rec[i] = line;                   // 64 contiguous bytes per lane, 4 KB per wave
             out.rect[i] = r.rect;
             out.depth[i] = r.r2.w;
+            out.mask[i] = r.mask;
         }
         out.tiles[i] = r.tiles;
     }
@@ -490,10 +495,10 @@ __global__ __launch_bounds__(COUNT_SHARDS) void finish_counts_kernel(const Count
 // Needs no pair buffer, so it is queued with the colour pass behind the counters and runs during the host round trip.
 template <class F>
 __device__ __forceinline__ void for_block_pairs(int64_t n, const u2* __restrict__ rect, const uint32_t* __restrict__ tiles,
-                                                const float* __restrict__ depth, int tiles_x, F f) {
+                                                const uint32_t* __restrict__ mask, const float* __restrict__ depth, int tiles_x, F f) {
     const int tid = threadIdx.x, lane = tid & 63;
     constexpr int K = BIN_GAUSS / 256;
-    uint32_t nt[K];
+    uint32_t nt[K], mk[K];
     u2 r[K];
     uint64_t payload[K];
 #pragma unroll
@@ -506,17 +511,19 @@ __device__ __forceinline__ void for_block_pairs(int64_t n, const u2* __restrict_
         const int64_t i = (int64_t)blockIdx.x * BIN_GAUSS + k * 256 + tid;
         r[k] = u2{0u, 0u};
         payload[k] = 0ull;
+        mk[k] = 0u;
         if (nt[k]) {
             r[k] = rect[i];
+            mk[k] = mask[i];
             if (depth) payload[k] = ((uint64_t)f2u(depth[i]) << 32) | (uint64_t)(uint32_t)i;
         }
     }
 #pragma unroll
-    for (int k = 0; k < K; ++k) for_each_list(r[k], nt[k], tiles_x, lane, payload[k], 0u, f);
+    for (int k = 0; k < K; ++k) for_each_list(r[k], nt[k], mk[k], tiles_x, lane, payload[k], 0u, f);
 }
 
 __global__ __launch_bounds__(256) void bin_count_kernel(int64_t n, const u2* __restrict__ rect, const uint32_t* __restrict__ tiles,
-                                                        int tiles_x, int nb, uint32_t* __restrict__ bin_total,
+                                                        const uint32_t* __restrict__ mask, int tiles_x, int nb, uint32_t* __restrict__ bin_total,
                                                         uint32_t* __restrict__ block_off, uint32_t* __restrict__ list_count,
                                                         uint2* __restrict__ ranges, int nl) {
     __shared__ uint32_t hist[MAX_BINS];
@@ -527,7 +534,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(int64_t n, const u2* __r
     }
     for (int b = tid; b < nb; b += 256) hist[b] = 0u;
     __syncthreads();
-    for_block_pairs(n, rect, tiles, nullptr, tiles_x, [&](uint32_t l, uint32_t, uint64_t, uint32_t) { atomicAdd(&hist[l >> BIN_SHIFT], 1u); });
+    for_block_pairs(n, rect, tiles, mask, nullptr, tiles_x, [&](uint32_t l, uint32_t, uint64_t, uint32_t) { atomicAdd(&hist[l >> BIN_SHIFT], 1u); });
     __syncthreads();
     for (int b = tid; b < nb; b += 256) {
         const uint32_t c = hist[b];
@@ -539,7 +546,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(int64_t n, const u2* __r
 // rank inside the block (LDS atomic).  The order inside a bin is arbitrary; the per-list sort by the unique payload makes
 // the final order deterministic.
 __global__ __launch_bounds__(256) void bin_scatter_kernel(int64_t n, const u2* __restrict__ rect, const uint32_t* __restrict__ tiles,
-                                                          const float* __restrict__ depth, int tiles_x, int nb,
+                                                          const uint32_t* __restrict__ mask, const float* __restrict__ depth, int tiles_x, int nb,
                                                           const uint32_t* __restrict__ bin_total, const uint32_t* __restrict__ block_off,
                                                           uint32_t* __restrict__ bin_start, uint32_t n_binned,
                                                           uint64_t* __restrict__ bvals) {
@@ -571,7 +578,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(int64_t n, const u2* _
         }
     }
     __syncthreads();
-    for_block_pairs(n, rect, tiles, depth, tiles_x, [&](uint32_t l, uint32_t, uint64_t pl, uint32_t) {
+    for_block_pairs(n, rect, tiles, mask, depth, tiles_x, [&](uint32_t l, uint32_t, uint64_t pl, uint32_t) {
         const uint32_t pos = atomicAdd(&cur[l >> BIN_SHIFT], 1u);
         if (pos < n_binned)                                 // defensive: never write past the caller's buffer
             bvals[pos] = pl | ((uint64_t)(l & ((1u << BIN_SHIFT) - 1u)) << ID_BITS);
@@ -1416,7 +1423,7 @@ int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_vie
     hipLaunchKernelGGL(camera_kernel, dim3(1), dim3(256), 0, st, c2w, ps.cam, ps.counts, ps.shards, ps.bin_total, (int)nb);
     LAUNCH_CHECK("camera_kernel");
     if (n > 0) {
-        Records out{ps.rec, ps.rect, ps.depth, ps.tiles, nullptr, nullptr};
+        Records out{ps.rec, ps.rect, ps.depth, ps.tiles, ps.mask, nullptr, nullptr};
         if (fused)
             hipLaunchKernelGGL((project_kernel<true, false>), dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, vk, out, ps.shards);
         else
@@ -1428,7 +1435,7 @@ int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_vie
     if (counts_host) HIP_TRY(hipMemcpyAsync(counts_host, ps.counts, sizeof(gsplat_counts), hipMemcpyDeviceToHost, st));
     if (counts_event) HIP_TRY(hipEventRecord((hipEvent_t)counts_event, st));
     if (n > 0) {                    // these two need no pair buffer: they run while the host waits for the counters
-        hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)n_bin_blocks(n)), dim3(256), 0, st, n, ps.rect, ps.tiles, vk.tiles_x, (int)nb,
+        hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)n_bin_blocks(n)), dim3(256), 0, st, n, ps.rect, ps.tiles, ps.mask, vk.tiles_x, (int)nb,
                            ps.bin_total, ps.block_off, ps.list_count, ps.ranges, (int)nl);
         LAUNCH_CHECK("bin_count_kernel");
         if (fused) {
@@ -1458,7 +1465,7 @@ int gsplat_bin(int64_t n, int64_t n_binned, const gsplat_view* v, const void* pr
     BinScratch sc = carve_bin_scratch(scratch, n_binned, nb);
     if (!scratch || sc.bytes > scratch_bytes) return fail(GSPLAT_ERR_WORKSPACE, "bin scratch too small");
     uint32_t* sorted_ids = (uint32_t*)bin_state;
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3((unsigned)n_bin_blocks(n)), dim3(256), 0, st, n, ps.rect, ps.tiles, ps.depth, vk.tiles_x,
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3((unsigned)n_bin_blocks(n)), dim3(256), 0, st, n, ps.rect, ps.tiles, ps.mask, ps.depth, vk.tiles_x,
                        (int)nb, ps.bin_total, ps.block_off, ps.bin_start, (uint32_t)n_binned, sc.bvals);
     LAUNCH_CHECK("bin_scatter_kernel");
     hipLaunchKernelGGL(split_count_kernel, dim3((unsigned)n_chunks(n_binned)), dim3(256), 0, st, (int)nb, ps.bin_start, sc.bvals,

@@ -12,11 +12,11 @@ extern "C" {
 // rect / tiles: the reference's own tile rectangle and pair count (F10/F11); brect / btiles: what the kernels bin
 // (tight box, 16 x 8 half-tile lists)
 void hm_project(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, float* rec64, uint32_t* rect, float* depth,
-                uint32_t* tiles, int32_t* vis, uint32_t* brect, uint32_t* btiles) {
+                uint32_t* tiles, int32_t* vis, uint32_t* brect, uint32_t* btiles, uint32_t* bmask) {
     Camera cam; build_camera(c2w, cam);
     const ViewK vk = make_viewk(*v);
     const bool fused = g->scale_raw != nullptr;
-    Records out{(Rec64*)rec64, (u2*)brect, depth, btiles, (u2*)rect, tiles};
+    Records out{(Rec64*)rec64, (u2*)brect, depth, btiles, bmask, (u2*)rect, tiles};
     for (int64_t i = 0; i < g->n; ++i) {
         ShCoefGlobal coef{fused ? g->f_dc + i * 3 : nullptr, fused ? g->f_rest + i * 45 : nullptr};
         vis[i] = project_one(i, *g, fused, coef, cam, vk, out);

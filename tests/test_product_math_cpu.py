@@ -51,12 +51,13 @@ def _project(hm, d, arrs, fused=True, color=None, sigma=None):
     vis = np.zeros(n, np.int32)
     brect = np.zeros((n, 2), np.uint32)
     btiles = np.zeros(n, np.uint32)
+    bmask = np.zeros(n, np.uint32)
     g = _gaussians(arrs, fused, color, sigma)
     c2w = np.ascontiguousarray(d["c2w"], np.float32)
     hm.hm_project(C.byref(g), _ptr(c2w), C.byref(view), _ptr(rec64), _ptr(rect), _ptr(depth), _ptr(tiles), _ptr(vis),
-                  _ptr(brect), _ptr(btiles))
+                  _ptr(brect), _ptr(btiles), _ptr(bmask))
     assert np.array_equal(depth[vis == 0], rec64[vis == 0, 11])
-    rec = [rec64[:, 0:4], rec64[:, 4:8], rec64[:, 8:12], rect, brect, btiles]
+    rec = [rec64[:, 0:4], rec64[:, 4:8], rec64[:, 8:12], rect, brect, btiles, bmask]
     return rec, tiles, vis, view, g, c2w
 
 
@@ -101,12 +102,17 @@ def test_forward_records_vs_reference_intermediates(hm, name):
     bl, bh, bt = rec[4][ids, 0], rec[4][ids, 1], rec[5][ids]
     br = np.stack([bl & 0xFFFF, bl >> 16, bh & 0xFFFF, bh >> 16], 1).astype(np.int32)
     has = bt > 0
-    assert np.all(bt[has] == ((br[:, 2] - br[:, 0] + 1) * (br[:, 3] - br[:, 1] + 1))[has])
+    bm = rec[6][ids]
+    area = (br[:, 2] - br[:, 0] + 1) * (br[:, 3] - br[:, 1] + 1)
+    small = has & (area <= 32)
+    assert np.all(bt[has & ~small] == area[has & ~small]) and np.all(bm[has & ~small] == 0xFFFFFFFF)
+    assert np.all(bt[small] == [bin(int(x)).count("1") for x in bm[small]])
+    assert np.all(bm[small] >> area[small].astype(np.uint32) == 0)
     assert np.all((br[has, 0] >= rect[has, 0]) & (br[has, 2] <= rect[has, 2]) & (br[has, 1] >= 2 * rect[has, 1]) &
                   (br[has, 3] <= 2 * rect[has, 3] + 1))
     H, W = d["H"], d["W"]
     ys, xs = np.mgrid[0:H, 0:W]
-    for k in range(0, len(ids), max(1, len(ids) // 60)):
+    for k in range(0, len(ids), max(1, len(ids) // 200)):
         du, dv = xs - float(d["im_u"][k]), ys - float(d["im_v"][k])
         q = con[k, 0, 0] * du * du + 2 * con[k, 0, 1] * du * dv + con[k, 1, 1] * dv * dv
         inside = q <= chi * (1 - 1e-6)
@@ -117,6 +123,9 @@ def test_forward_records_vs_reference_intermediates(hm, name):
         assert bt[k] > 0, k
         lx, ly = xs[inside] // 16, ys[inside] // 8
         assert lx.min() >= br[k, 0] and lx.max() <= br[k, 2] and ly.min() >= br[k, 1] and ly.max() <= br[k, 3], k
+        if area[k] <= 32:              # every list that holds such a pixel has its mask bit set
+            bit = (ly - br[k, 1]) * (br[k, 2] - br[k, 0] + 1) + (lx - br[k, 0])
+            assert np.all((int(bm[k]) >> bit) & 1), k
 
 
 def _oracle_stage_grads(d, fused=True, color=None, sigma=None, seed=0):
