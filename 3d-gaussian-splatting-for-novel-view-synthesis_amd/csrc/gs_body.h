@@ -146,9 +146,12 @@ GS_HD RecOut project_core(const GaussIn& in, bool fused, Coef coef, const Camera
 // K7 core.  r9 = (g_u, g_v, g_A11, g_A12, g_A22, g_opacity, g_r, g_g, g_b) of a visible Gaussian.
 // emit_sh(k, ch, val) receives dL/d(SH coefficient) for k = 0..15 (k = 0 -> f_dc); it is called for every (k, ch),
 // with zeros for a Gaussian that is not visible, so that every output row is written.
+// moments = true (what raster_backward_kernel accumulates): r9[0..4] = (Sx, Sy, Sxx, Sxy, Syy), the moments sum du^a dv^b dL/dq
+// over the pixels; with q = A11 du^2 + 2 A12 du dv + A22 dv^2 and du = px - u:  d u = -2 (A11 Sx + A12 Sy),
+// d v = -2 (A12 Sx + A22 Sy), d A11 = Sxx, d A12 = 2 Sxy, d A22 = Syy.  moments = false: r9[0..4] are those gradients.
 template <class Coef, class Emit>
 GS_HD GradOut project_backward_core(const GaussIn& in, bool fused, Coef coef, Emit emit_sh, const Camera& cam, const ViewK& vk,
-                                    bool vis, const float r9[9]) {
+                                    bool vis, const float r9[9], bool moments = false) {
     GradOut g;
     for (int k = 0; k < 3; ++k) { g.p[k] = 0.f; g.sr[k] = 0.f; g.col[k] = 0.f; }
     for (int k = 0; k < 4; ++k) g.qr[k] = 0.f;
@@ -161,7 +164,13 @@ GS_HD GradOut project_backward_core(const GaussIn& in, bool fused, Coef coef, Em
         else load_cov6(in.S9, S);
         Proj o; ProjMid m;
         project_gaussian(in.p, S, in.o_raw, cam, vk, o, m);
-        project_gaussian_backward(m, o, cam, vk, r9[0], r9[1], r9[2], r9[3], r9[4], r9[5], g.p, g.S9, g.o_raw);
+        float gu = r9[0], gv = r9[1], ga = r9[2], gb = r9[3], gc = r9[4];
+        if (moments) {
+            gu = -2.f * (o.A11 * r9[0] + o.A12 * r9[1]);
+            gv = -2.f * (o.A12 * r9[0] + o.A22 * r9[1]);
+            gb = 2.f * r9[3];
+        }
+        project_gaussian_backward(m, o, cam, vk, gu, gv, ga, gb, gc, r9[5], g.p, g.S9, g.o_raw);
         g.col[0] = r9[6]; g.col[1] = r9[7]; g.col[2] = r9[8];
         if (fused) {
             cov_from_params_backward(in.qr, cm, g.S9, g.sr, g.qr);

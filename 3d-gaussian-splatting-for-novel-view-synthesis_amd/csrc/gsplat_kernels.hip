@@ -1204,12 +1204,13 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
                     const v2f dvq = dv * dq;
                     const float dqs = dq.x + dq.y, dvqs = dvq.x + dvq.y;
                     const v2f aA22 = dv * dvq;
-                    // the staged conic is k * (A11, 2 A12, A22): undo the scale with 1/k for the two position gradients
-                    r[0] = -(2.0f * a.z * du * dqs + a.w * dvqs) * (1.0f / QK);    // d u
-                    r[1] = -(a.w * du * dqs + 2.0f * b.x * dvqs) * (1.0f / QK);    // d v
-                    r[2] = du * du * dqs;                                          // d A11
-                    r[3] = 2.0f * du * dvqs;                                       // d A12
-                    r[4] = aA22.x + aA22.y;                                        // d A22
+                    // first and second moments of dL/dq over the wave's pixels; project_backward_kernel turns them into
+                    // the gradients of (u, v, A11, A12, A22): d u = -2 (A11 Sx + A12 Sy), d A12 = 2 Sxy, ...
+                    r[0] = du * dqs;                                               // Sx  = sum du dq
+                    r[1] = dvqs;                                                   // Sy  = sum dv dq
+                    r[2] = du * r[0];                                              // Sxx = sum du^2 dq
+                    r[3] = du * dvqs;                                              // Sxy = sum du dv dq
+                    r[4] = aA22.x + aA22.y;                                        // Syy = sum dv^2 dq
                     r[5] = ao.x + ao.y;                                            // d opacity
                     r[6] = ar.x + ar.y; r[7] = ag.x + ag.y; r[8] = ab.x + ab.y;    // d rgb
                 }
@@ -1282,7 +1283,7 @@ __global__ __launch_bounds__(64) void project_backward_kernel(gsplat_gaussians g
     if (vis) {
         const GaussIn in = gauss_from_lds<FUSED>(s, lane);
         go = project_backward_core(in, FUSED, ShCoefLds{s_dc + lane * 3, s_rest + lane * 45},
-                                   ShEmitLds{s_dc + lane * 3, s_rest + lane * 45}, cam, vk, true, r9);
+                                   ShEmitLds{s_dc + lane * 3, s_rest + lane * 45}, cam, vk, true, r9, true);
     } else {
 #pragma unroll
         for (int k = 0; k < 3; ++k) { go.p[k] = 0.f; go.sr[k] = 0.f; go.col[k] = 0.f; }

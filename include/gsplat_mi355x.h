@@ -138,8 +138,9 @@ int gsplat_rasterize_forward(int64_t n, int64_t n_binned, const gsplat_view* v, 
                              const void* bin_state, float* image, float* accum, void* stream);
 
 /* ---- backward ---------------------------------------------------------------------------------- */
-/* B1: gradient of the compositing w.r.t. the per-Gaussian 2D quantities.  grad2d is [n,16] floats
- * (u, v, conic a, b, c, opacity, r, g, b, pad...) and is zeroed by this call before accumulation.     */
+/* B1: gradient of the compositing w.r.t. the per-Gaussian 2D quantities.  grad2d is [n,16] floats, private to the
+ * library (moments of dL/dq over the pixels for the centre and the conic, then opacity, r, g, b, padding); it is zeroed
+ * by this call before accumulation and consumed by gsplat_project_backward.                                          */
 int gsplat_rasterize_backward(int64_t n, int64_t n_binned, const gsplat_view* v, const void* project_state,
                               const void* bin_state, const float* accum, const float* grad_image,
                               float* grad2d, void* stream);
