@@ -231,19 +231,18 @@ struct Proj {
 // inclusive)?  q is convex: if the centre is outside the rectangle the minimum lies on one of the four edges, where it is
 // a clamped 1-D quadratic.  Conservative (a relative 1e-3 margin on chi dwarfs the fp32 differences with the
 // rasterizer's own evaluation of q), so a "no" means alpha = 0 on every pixel of the rectangle.
-GS_HD bool ellipse_touches_rect(const Proj& o, float chi, float x0, float y0, float x1, float y1) {
+GS_HD bool ellipse_touches_rect(const Proj& o, float chi_pad, float r12_22, float r12_11, float x0, float y0, float x1, float y1) {
     const float dx0 = x0 - o.u, dx1 = x1 - o.u, dy0 = y0 - o.v, dy1 = y1 - o.v;
     if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;
-    if (!(o.A11 > 0.f && o.A22 > 0.f)) return true;
     float best = 3.0e38f;
     const float xs[2] = {dx0, dx1}, ys[2] = {dy0, dy1};
     for (int k = 0; k < 2; ++k) {
-        const float X = xs[k], t = clampf_(-o.A12 * X / o.A22, dy0, dy1);
-        best = fminf(best, o.A11 * X * X + 2.f * o.A12 * X * t + o.A22 * t * t);
-        const float Y = ys[k], s_ = clampf_(-o.A12 * Y / o.A11, dx0, dx1);
-        best = fminf(best, o.A11 * s_ * s_ + 2.f * o.A12 * s_ * Y + o.A22 * Y * Y);
+        const float X = xs[k], t = clampf_(r12_22 * X, dy0, dy1);             // minimiser of q along the edge x = X
+        best = fminf(best, o.A11 * X * X + (2.f * o.A12 * X + o.A22 * t) * t);
+        const float Y = ys[k], s_ = clampf_(r12_11 * Y, dx0, dx1);            // ... along the edge y = Y
+        best = fminf(best, o.A22 * Y * Y + (2.f * o.A12 * Y + o.A11 * s_) * s_);
     }
-    return !(best > chi * 1.001f + 1e-4f);          // NaN -> true
+    return !(best > chi_pad);          // NaN -> true
 }
 
 // Bit k (row-major inside the binned rectangle) = the Gaussian can touch list k.  Rectangles of more than 32 lists are
@@ -251,13 +250,14 @@ GS_HD bool ellipse_touches_rect(const Proj& o, float chi, float x0, float y0, fl
 GS_HD uint32_t binned_mask(const Proj& o, const ViewK& vk) {
     if (o.bx1 < o.bx0 || o.by1 < o.by0) return 0u;
     const int w = o.bx1 - o.bx0 + 1, h = o.by1 - o.by0 + 1;
-    if (w * h > 32) return 0xFFFFFFFFu;
+    if (w * h > 32 || !(o.A11 > 0.f && o.A22 > 0.f)) return 0xFFFFFFFFu >> (w * h > 32 ? 0 : 32 - w * h);
     const int half = vk.tile / 2;
+    const float chi_pad = vk.chi_clip * 1.001f + 1e-4f, r12_22 = -o.A12 / o.A22, r12_11 = -o.A12 / o.A11;
     uint32_t m = 0u;
     int k = 0;
     for (int y = o.by0; y <= o.by1; ++y)
         for (int x = o.bx0; x <= o.bx1; ++x, ++k)
-            if (ellipse_touches_rect(o, vk.chi_clip, (float)(x * vk.tile), (float)(y * half), (float)(x * vk.tile + vk.tile - 1),
+            if (ellipse_touches_rect(o, chi_pad, r12_22, r12_11, (float)(x * vk.tile), (float)(y * half), (float)(x * vk.tile + vk.tile - 1),
                                      (float)(y * half + half - 1)))
                 m |= 1u << k;
     return m;
