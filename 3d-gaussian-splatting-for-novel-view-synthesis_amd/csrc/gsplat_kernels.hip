@@ -1256,7 +1256,7 @@ struct ShEmitLds {
 template <bool FUSED>
 __global__ __launch_bounds__(64) void project_backward_kernel(gsplat_gaussians g, const Camera* __restrict__ camp, ViewK vk,
                                                               const uint32_t* __restrict__ tiles, const float* __restrict__ grad2d,
-                                                              gsplat_gaussian_grads out) {
+                                                              gsplat_gaussian_grads out, bool factored) {
     __shared__ ProjectLds s;
     __shared__ float s_dc[FUSED ? 64 * 3 : 4];
     __shared__ float s_rest[FUSED ? 64 * 45 : 4];
@@ -1319,12 +1319,61 @@ __global__ __launch_bounds__(64) void project_backward_kernel(gsplat_gaussians g
     if (FUSED) {
         unstage_rows<4>(out.q_raw, s.a, row0, g.n, lane);
         unstage_rows<3>(out.scale_raw, s.b, row0, g.n, lane);
-        unstage_rows<3>(out.f_dc, s_dc, row0, g.n, lane);
-        unstage_rows<45>(out.f_rest, s_rest, row0, g.n, lane);
+        if (factored) {
+            // d L / d f_dc = (d L / d colour logit) * Y0: hand out the 3 logit gradients instead of the 48 SH gradients
+            // (gsplat_sh_accumulate rebuilds those, for any number of views, from logit gradients and view directions)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) s_dc[lane * 3 + k] *= 1.0f / GS_K0;      // each lane its own slots: no barrier needed
+            __syncthreads();
+            unstage_rows<3>(out.color, s_dc, row0, g.n, lane);
+        } else {
+            unstage_rows<3>(out.f_dc, s_dc, row0, g.n, lane);
+            unstage_rows<45>(out.f_rest, s_rest, row0, g.n, lane);
+        }
     } else {
         unstage_rows<9>(out.sigma, s.a, row0, g.n, lane);
         unstage_rows<3>(out.color, s.b, row0, g.n, lane);
     }
+}
+
+// ---- SH gradients from logit gradients (data-parallel exchange) ---------------------------------------
+// grad f_dc[i, ch] = scale * sum_v glogit[v, i, ch] * Y0,  grad f_rest[i, ch * 15 + k - 1] = scale * sum_v glogit[v, i, ch] * Y_k(d_v(i)),
+// d_v(i) = unit vector from camera v's position to Gaussian i (spherical_harmonics.py:132-133).
+__global__ __launch_bounds__(64) void sh_accumulate_kernel(int64_t n, int n_views, const float* __restrict__ pos, const float* __restrict__ eyes,
+                                                           const float* __restrict__ glogit, float scale, float* __restrict__ grad_f_dc,
+                                                           float* __restrict__ grad_f_rest) {
+    __shared__ float s_pos[64 * 3], s_dc[64 * 3], s_rest[64 * 45];
+    const int lane = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * 64, i = row0 + lane;
+    stage_rows<3>(s_pos, pos, row0, n, lane);
+    __syncthreads();
+    float acc[48];
+#pragma unroll
+    for (int k = 0; k < 48; ++k) acc[k] = 0.f;
+    if (i < n) {
+        const float p[3] = {s_pos[lane * 3], s_pos[lane * 3 + 1], s_pos[lane * 3 + 2]};
+        for (int v = 0; v < n_views; ++v) {
+            const float* gl = glogit + ((int64_t)v * n + i) * 3;
+            const float g0 = gl[0], g1 = gl[1], g2 = gl[2];
+            if (g0 == 0.f && g1 == 0.f && g2 == 0.f) continue;       // not binned in this view
+            const float eye[3] = {eyes[v * 3], eyes[v * 3 + 1], eyes[v * 3 + 2]};
+            ShMid sm;
+            sh_basis(p, eye, sm);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                acc[k] += g0 * sm.Y[k]; acc[16 + k] += g1 * sm.Y[k]; acc[32 + k] += g2 * sm.Y[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        s_dc[lane * 3 + ch] = scale * acc[ch * 16];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) s_rest[lane * 45 + ch * 15 + (k - 1)] = scale * acc[ch * 16 + k];
+    }
+    __syncthreads();
+    unstage_rows<3>(grad_f_dc, s_dc, row0, n, lane);
+    unstage_rows<45>(grad_f_rest, s_rest, row0, n, lane);
 }
 
 // ---- stand-alone ops -------------------------------------------------------------------------------
@@ -1543,15 +1592,18 @@ int gsplat_project_backward(const gsplat_gaussians* g, const float* c2w, const g
     if (!c2w || !project_state || !grad2d || !out) return fail(GSPLAT_ERR_BAD_ARG, "NULL argument");
     if (g->n == 0) return GSPLAT_OK;
     if (!out->pos || !out->opacity_raw) return fail(GSPLAT_ERR_BAD_ARG, "grad pos / opacity_raw is NULL");
-    if (fused && !(out->scale_raw && out->q_raw && out->f_dc && out->f_rest)) return fail(GSPLAT_ERR_BAD_ARG, "fused grads incomplete");
+    // fused inputs, f_dc and f_rest NULL, color given: hand out the colour-logit gradients instead of the SH gradients
+    const bool factored = fused && !out->f_dc && !out->f_rest && out->color;
+    if (fused && !factored && !(out->scale_raw && out->q_raw && out->f_dc && out->f_rest)) return fail(GSPLAT_ERR_BAD_ARG, "fused grads incomplete");
+    if (factored && !(out->scale_raw && out->q_raw)) return fail(GSPLAT_ERR_BAD_ARG, "fused grads incomplete");
     if (!fused && !(out->color && out->sigma)) return fail(GSPLAT_ERR_BAD_ARG, "grad color / sigma is NULL");
     hipStream_t st = (hipStream_t)stream_;
     ProjectState ps = carve_project((void*)project_state, g->n, n_lists(v));
     const ViewK vk = make_viewk(*v);
     if (fused)
-        hipLaunchKernelGGL(project_backward_kernel<true>, dim3(blocks64(g->n)), dim3(64), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out);
+        hipLaunchKernelGGL(project_backward_kernel<true>, dim3(blocks64(g->n)), dim3(64), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out, factored);
     else
-        hipLaunchKernelGGL(project_backward_kernel<false>, dim3(blocks64(g->n)), dim3(64), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out);
+        hipLaunchKernelGGL(project_backward_kernel<false>, dim3(blocks64(g->n)), dim3(64), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out, false);
     LAUNCH_CHECK("project_backward_kernel");
     return GSPLAT_OK;
 }
@@ -1595,6 +1647,18 @@ int gsplat_evaluate_sh_backward(int64_t n, const float* f_dc, const float* f_res
     hipLaunchKernelGGL(evaluate_sh_backward_kernel, dim3(blocks256(n)), dim3(256), 0, (hipStream_t)stream_, n, f_dc, f_rest, points, c2w,
                        grad_color, grad_f_dc, grad_f_rest, grad_points);
     LAUNCH_CHECK("evaluate_sh_backward_kernel");
+    return GSPLAT_OK;
+}
+
+int gsplat_sh_accumulate(int64_t n, int32_t n_views, const float* pos, const float* eyes, const float* grad_logit, float scale,
+                         float* grad_f_dc, float* grad_f_rest, void* stream_) {
+    if (n < 0 || n_views < 0) return fail(GSPLAT_ERR_BAD_ARG, "n / n_views < 0");
+    if (n == 0) return GSPLAT_OK;
+    if (!pos || !grad_f_dc || !grad_f_rest || (n_views > 0 && (!eyes || !grad_logit))) return fail(GSPLAT_ERR_BAD_ARG, "NULL argument");
+    if (!aligned16(pos) || !aligned16(grad_f_dc) || !aligned16(grad_f_rest)) return fail(GSPLAT_ERR_BAD_ARG, "arrays must be 16-byte aligned");
+    hipLaunchKernelGGL(sh_accumulate_kernel, dim3(blocks64(n)), dim3(64), 0, (hipStream_t)stream_, n, (int)n_views, pos, eyes, grad_logit,
+                       scale, grad_f_dc, grad_f_rest);
+    LAUNCH_CHECK("sh_accumulate_kernel");
     return GSPLAT_OK;
 }
 

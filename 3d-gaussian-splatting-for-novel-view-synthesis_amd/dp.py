@@ -106,3 +106,94 @@ def data_parallel_step(render_fn, params, views, targets_grad_fn, world_views, g
         grads.append(p.grad)
     allreduce_gradients(grads, world_views, group)
     return total
+
+
+def _all_gather_cat(t, group=None):
+    """Concatenation over ranks along dim 0 of equally shaped tensors (RCCL all-gather; gloo with GPU tensors is staged
+    through the host, for rehearsals only)."""
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) == "gloo" and t.is_cuda:
+        parts = [torch.empty(t.shape, dtype=t.dtype) for _ in range(world)]
+        dist.all_gather(parts, t.cpu(), group=group)
+        return torch.cat(parts, 0).to(t.device)
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+    return out
+
+
+class FactoredExchange:
+    """Gradient exchange that moves 2.6x fewer bytes than the all-reduce of all six tensors (8 views): per view the
+    SH-coefficient gradient (192 of the 236 bytes per Gaussian) is the outer product of the 3 colour-logit gradients with
+    the 16 SH basis values of the view direction, which every rank can evaluate itself.  So the ranks all-reduce only the
+    gradients of pos / opacity_raw / scale_raw / q_raw (44 B per Gaussian), all-gather the logit gradients of their views
+    (12 B per Gaussian and view) and camera positions, and rebuild sum_v g_v (x) Y(d_v) locally (gsplat_sh_accumulate).
+    Same fp32 arithmetic as the plain path up to the order of the sum over views.
+
+        ex = FactoredExchange(params, world_views)        # params: dict name -> leaf tensor
+        with ex:                                            # render backward hands logit gradients to `ex`
+            for view in my_views: loss(render_gaussians(...)).backward()
+        ex.finish()                                         # collectives + rebuild; every p.grad is final and identical on all ranks
+
+    Every rank must render the same number of views.  Works unchanged in a single process (no collective)."""
+
+    SMALL = ("pos", "opacity_raw", "scale_raw", "q_raw")
+
+    def __init__(self, params, world_views, group=None, accumulate=None):
+        self.params, self.world_views, self.group = params, world_views, group
+        self.logits, self.eyes = [], []
+        self._accumulate = accumulate
+
+    def add(self, grad_logit, eye):
+        self.logits.append(grad_logit)
+        self.eyes.append(eye.detach().to(torch.float32))
+
+    def __enter__(self):
+        from . import ops
+        ops.set_sh_gradient_sink(self)
+        return self
+
+    def __exit__(self, *exc):
+        from . import ops
+        ops.set_sh_gradient_sink(None)
+        return False
+
+    def finish(self):
+        p = self.params
+        small = []
+        for k in self.SMALL:
+            if p[k].grad is None:
+                p[k].grad = torch.zeros_like(p[k])
+            small.append(p[k].grad)
+        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        n = p["pos"].shape[0]
+        if self.logits:
+            logits, eyes = torch.stack(self.logits), torch.stack(self.eyes)
+        else:
+            logits = torch.zeros((0, n, 3), dtype=torch.float32, device=p["pos"].device)
+            eyes = torch.zeros((0, 3), dtype=torch.float32, device=p["pos"].device)
+        if distributed:
+            # the four small gradients are views of one flat buffer when they come from the render backward: one async
+            # all-reduce, overlapped with the all-gather of the logit gradients
+            base = _common_base(small)
+            work = None
+            if base is not None:
+                work = dist.all_reduce(base, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            logits, eyes = _all_gather_cat(logits, self.group), _all_gather_cat(eyes, self.group)
+            if work is not None:
+                work.wait()
+                if self.world_views != 1:
+                    base.mul_(1.0 / self.world_views)
+            else:
+                allreduce_gradients(small, self.world_views, self.group)
+        elif self.world_views != 1:
+            for g in small:
+                g.mul_(1.0 / self.world_views)
+        acc = self._accumulate
+        if acc is None:
+            from . import ops
+            acc = ops.sh_accumulate
+        g_dc, g_rest = acc(p["pos"].detach(), eyes, logits, 1.0 / self.world_views)
+        for k, g in (("f_dc", g_dc), ("f_rest", g_rest)):
+            g = g.to(p[k].dtype)
+            p[k].grad = g if p[k].grad is None else p[k].grad + g
+        self.logits, self.eyes = [], []

@@ -213,12 +213,28 @@ def _flat_like(ins):
     return {k: flat[offs[k]:offs[k] + v.numel()].view(v.shape) for k, v in ins.items()}
 
 
+# Data-parallel exchange of the SH gradients in factored form (dp.FactoredExchange): while a sink is installed
+# the render backward of the fused entry hands the 3 colour-logit gradients per Gaussian to the sink instead of
+# computing the 48 SH-coefficient gradients, and returns no gradient for f_dc / f_rest.
+_sh_sink = None
+
+
+def set_sh_gradient_sink(sink):
+    """sink: object with .add(grad_logit[N,3], eye[3] device tensor), or None to restore the ordinary backward."""
+    global _sh_sink
+    _sh_sink = sink
+
+
 def _backward_impl(fr, grad_image):
     """Returns a dict name -> fp32 gradient tensor for every input of the forward call."""
     lib = _abi.lib()
     ins = fr.inputs
     dev = ins["pos"].device
+    factored = fr.fused and _sh_sink is not None
     if fr.empty or fr.n == 0:
+        if factored:
+            _sh_sink.add(torch.zeros((fr.n, 3), dtype=torch.float32, device=dev), fr.c2w[:3, 3])
+            return {k: (None if k in ("f_dc", "f_rest") else torch.zeros_like(v)) for k, v in ins.items()}
         return {k: torch.zeros_like(v) for k, v in ins.items()}
     gi = _f32(grad_image, (fr.view.H, fr.view.W, 3), "grad_image")
     st = _stream_ptr(dev)
@@ -227,14 +243,34 @@ def _backward_impl(fr, grad_image):
         with _stage("raster_backward"):
             _abi.check(lib.gsplat_rasterize_backward(fr.n, fr.n_pairs, C.byref(fr.view), _p(fr.proj_state), _p(fr.bin_state),
                                                      _p(fr.accum), _p(gi), _p(grad2d), st), "gsplat_rasterize_backward")
-        out = _flat_like(ins)
+        out = _flat_like({k: v for k, v in ins.items() if not (factored and k in ("f_dc", "f_rest"))})
+        glogit = torch.empty((fr.n, 3), dtype=torch.float32, device=dev) if factored else None
         g = _make_gaussians(fr.n, **ins)
-        gg = _abi.GaussianGrads(_p(out["pos"]), _p(out["opacity_raw"]), _p(out.get("color")), _p(out.get("sigma")),
+        gg = _abi.GaussianGrads(_p(out["pos"]), _p(out["opacity_raw"]), _p(glogit if factored else out.get("color")), _p(out.get("sigma")),
                                 _p(out.get("scale_raw")), _p(out.get("q_raw")), _p(out.get("f_dc")), _p(out.get("f_rest")))
         with _stage("project_backward"):
             _abi.check(lib.gsplat_project_backward(C.byref(g), _p(fr.c2w), C.byref(fr.view), _p(fr.proj_state), _p(grad2d),
                                                    C.byref(gg), st), "gsplat_project_backward")
+    if factored:
+        _sh_sink.add(glogit, fr.c2w[:3, 3])
+        out["f_dc"] = out["f_rest"] = None
     return out
+
+
+def sh_accumulate(pos, eyes, grad_logit, scale=1.0):
+    """(grad_f_dc [N,3], grad_f_rest [N,45]) = scale * sum over views of grad_logit[v] (x) Y(direction from eyes[v] to pos)."""
+    lib = _abi.lib()
+    n = pos.shape[0]
+    v = grad_logit.shape[0]
+    pos32, eyes32, gl32 = _f32(pos, (n, 3), "pos"), _f32(eyes, (v, 3), "eyes"), _f32(grad_logit, (v, n, 3), "grad_logit")
+    dev = pos32.device
+    with torch.cuda.device(dev):
+        off = (n * 3 + 63) // 64 * 64                     # both views 256-byte aligned inside one buffer
+        flat = torch.empty(off + n * 45, dtype=torch.float32, device=dev)
+        g_dc, g_rest = flat[:n * 3].view(n, 3), flat[off:off + n * 45].view(n, 45)
+        _abi.check(lib.gsplat_sh_accumulate(n, v, _p(pos32), _p(eyes32), _p(gl32), float(scale), _p(g_dc), _p(g_rest),
+                                            _stream_ptr(dev)), "gsplat_sh_accumulate")
+    return g_dc, g_rest
 
 
 class _RenderFn(torch.autograd.Function):
@@ -262,6 +298,9 @@ class _RenderFn(torch.autograd.Function):
                 outs.append(None)
                 continue
             t = g[nm]
+            if t is None:                     # f_dc / f_rest while a factored-exchange sink is installed
+                outs.append(None)
+                continue
             if nm == "opacity_raw":
                 t = t.reshape(ctx.opa_shape)
             outs.append(t if ctx.dtypes[i] == torch.float32 else t.to(ctx.dtypes[i]))

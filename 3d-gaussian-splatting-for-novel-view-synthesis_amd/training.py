@@ -93,6 +93,10 @@ class Trainer:
         self.optimizer.zero_grad()
         dev = m.pos.device
         acc = torch.zeros(3, dtype=torch.float32, device=dev)
+        # data parallel: SH gradients travel in factored form (dp.FactoredExchange, 2.6x fewer bytes over xGMI at 8 views)
+        exchange = dp.FactoredExchange(m.get_params(), world_views=1, group=self.group) if world > 1 else None
+        if exchange is not None:
+            exchange.__enter__()
         for v in views:
             image_gt = torch.as_tensor(v['image']).to(dev)
             c2w = torch.as_tensor(v['c2w'], dtype=torch.float32).to(dev)
@@ -101,13 +105,14 @@ class Trainer:
             loss, vals = losses.compute_loss_device(rendered, image_gt, c.lambda_l1, c.lambda_ssim)
             (loss / n_global).backward()
             acc += vals / n_global
+        if exchange is not None:
+            exchange.__exit__(None, None, None)
+            exchange.finish()                 # the loss was already divided by the global batch: world_views = 1
         names = dp.PARAM_NAMES
         for k in names:
             p = getattr(m, k)
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
-        if world > 1:
-            dp.allreduce_gradients([getattr(m, k).grad for k in names], world_views=1, group=self.group)
         self.optimizer.clip_grad_norm_(m.pos, max_norm=1.0)
         self.optimizer.step()
         densified = False

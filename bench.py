@@ -171,6 +171,8 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=256)
     ap.add_argument("--cpu-budget", type=int, default=150, help="seconds allowed for the CPU baseline leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
+    ap.add_argument("--exchange", default="factored", choices=("factored", "allreduce"),
+                    help="N > 1: SH gradients as logit gradients + local rebuild (DESIGN.md §7), or one all-reduce of all six tensors")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
@@ -220,9 +222,17 @@ def main():
         if need_grad:
             for p in params.values():
                 p.grad = None
-            img = gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args)
-            img.backward(gimg)
-            if world > 1:
+            if world > 1 and args.exchange == "factored":
+                with dp.FactoredExchange(params, world_views=world) as ex:
+                    img = gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args)
+                    img.backward(gimg)
+                ex.finish()
+                info["allreduce"] = "factored: all-reduce of pos/opacity/scale/rotation gradients (44 B per Gaussian) + all-gather " \
+                                    "of colour-logit gradients (12 B per Gaussian and view) + local SH rebuild"
+            else:
+                img = gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args)
+                img.backward(gimg)
+            if world > 1 and args.exchange == "allreduce":
                 grads = [params[k].grad for k in NAMES]
                 info["allreduce"] = "one flat buffer, single collective" if dp._common_base(grads) is not None else "2 buckets"
                 dp.allreduce_gradients(grads, world_views=world)
@@ -287,7 +297,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"SURVEY §8d config {args.config}: {N} Gaussians, {W}x{H}, SH degree 3, "
                                    f"{'forward+backward' if need_grad else 'forward only'}, one camera view per GPU per step"
-                                   + (", RCCL all-reduce of 6 gradient tensors" if world > 1 and need_grad else ""),
+                                   + (", gradient exchange over RCCL" if world > 1 and need_grad else ""),
                        "N": N, "V": V, "P": P, "tiles": math.ceil(H / 16) * math.ceil(W / 16),
                        "parallelism": f"dp{world} by camera view", "allreduce": info["allreduce"]},
             "fps": world * args.steps / elapsed,

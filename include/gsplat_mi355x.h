@@ -145,10 +145,21 @@ int gsplat_rasterize_backward(int64_t n, int64_t n_binned, const gsplat_view* v,
                               const void* bin_state, const float* accum, const float* grad_image,
                               float* grad2d, void* stream);
 
-/* B2 (+B3 when fused): chain the 2D gradients back to the inputs of gsplat_project.                   */
+/* B2 (+B3 when fused): chain the 2D gradients back to the inputs of gsplat_project.
+ * Factored form (fused inputs; out->f_dc and out->f_rest NULL, out->color given): instead of the 48 SH-coefficient
+ * gradients per Gaussian, out->color[n,3] receives the gradient w.r.t. the colour LOGIT (the sigmoid's argument,
+ * spherical_harmonics.py:166); gsplat_sh_accumulate turns logit gradients of any number of views into SH gradients.  */
 int gsplat_project_backward(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v,
                             const void* project_state, const float* grad2d, const gsplat_gaussian_grads* out,
                             void* stream);
+
+/* Data-parallel exchange helper: per view the SH-coefficient gradient is the outer product of the 3
+ * colour-logit gradients with the 16 SH basis values of the view direction, so ranks exchange 12 B per Gaussian and view
+ * instead of 192 B per Gaussian and rebuild the sum here:
+ *   grad_f_dc[i,ch] = scale * sum_v grad_logit[v,i,ch] * Y_0,  grad_f_rest[i, ch*15 + k-1] = scale * sum_v grad_logit[v,i,ch] * Y_k(d_v(i))
+ * pos[n,3]; eyes[n_views,3] = camera positions (c2w[:3,3]) on the DEVICE; grad_logit[n_views,n,3].                        */
+int gsplat_sh_accumulate(int64_t n, int32_t n_views, const float* pos, const float* eyes, const float* grad_logit,
+                         float scale, float* grad_f_dc, float* grad_f_rest, void* stream);
 
 /* ---- the two small exported functions as stand-alone ops --------------------------------------- */
 int gsplat_build_sigma(int64_t n, const float* scale_raw, const float* q_raw, float* sigma, void* stream);

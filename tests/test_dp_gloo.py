@@ -82,3 +82,71 @@ def test_single_process_scaling_and_sharding():
     dp.allreduce_gradients(g, world_views=4)
     assert torch.allclose(g[0], torch.full((4, 3), 0.25))
     assert dp.shard_views(8, 3, 8) == [3] and dp.shard_views(8, 1, 2) == [1, 3, 5, 7] and dp.shard_views(2, 3, 4) == []
+
+
+def _cpu_sh_accumulate(pos, eyes, logits, scale):
+    """Reference for gsplat_sh_accumulate with the oracle's SH basis (test infrastructure)."""
+    from oracle import torch_port as tp
+    n = pos.shape[0]
+    acc = torch.zeros(n, 16, 3, dtype=torch.float64)
+    for v in range(logits.shape[0]):
+        d = pos.double() - eyes[v].double()
+        d = d / (d.norm(dim=-1, keepdim=True) + 1e-8)
+        acc += tp.sh_basis(d).unsqueeze(-1) * logits[v].double().unsqueeze(1)
+    acc = acc * scale
+    return acc[:, 0, :].float(), acc[:, 1:, :].transpose(1, 2).reshape(n, 45).float()
+
+
+def _factored_inputs(rank, n=257, views=2):
+    g = torch.Generator().manual_seed(500 + rank)
+    logits = [torch.randn(n, 3, generator=g) for _ in range(views)]
+    eyes = [torch.randn(3, generator=g) * 3 for _ in range(views)]
+    small = {k: torch.randn(*SHAPES[k], generator=g) for k in ("pos", "opacity_raw", "scale_raw", "q_raw")}
+    return logits, eyes, small
+
+
+def _factored_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dp = importlib.import_module(PKG + ".dp")
+    pos = torch.randn(257, 3, generator=torch.Generator().manual_seed(7))          # replicated parameters
+    params = {k: torch.zeros(*s, requires_grad=True) for k, s in SHAPES.items()}
+    params["pos"] = pos.clone().requires_grad_(True)
+    logits, eyes, small = _factored_inputs(rank)
+    ex = dp.FactoredExchange(params, world_views=2 * world, accumulate=_cpu_sh_accumulate)
+    for k, g in small.items():                   # what the render backward leaves in .grad on this rank
+        params[k].grad = g.clone()
+    for gl, e in zip(logits, eyes):              # ... and what it hands to the sink, one entry per view
+        ex.add(gl, e)
+    ex.finish()
+    q.put((rank, {k: p.grad.numpy().copy() for k, p in params.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_factored_exchange_world2():
+    """The factored exchange (all-reduce of 44 B + all-gather of the logit gradients + local rebuild) gives every rank the
+    gradients the plain all-reduce of all six tensors would give."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_factored_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    pos = torch.randn(257, 3, generator=torch.Generator().manual_seed(7))
+    ins = [_factored_inputs(r) for r in range(world)]
+    all_logits = torch.stack([gl for logits, _, _ in ins for gl in logits])
+    all_eyes = torch.stack([e for _, eyes, _ in ins for e in eyes])
+    e_dc, e_rest = _cpu_sh_accumulate(pos, all_eyes, all_logits, 1.0 / (2 * world))
+    for rank in range(world):
+        g = got[rank]
+        for k in ("pos", "opacity_raw", "scale_raw", "q_raw"):
+            expect = sum(ins[r][2][k] for r in range(world)) / (2 * world)
+            assert torch.allclose(torch.from_numpy(g[k]), expect, atol=1e-6), k
+        assert torch.allclose(torch.from_numpy(g["f_dc"]), e_dc, atol=1e-6)
+        assert torch.allclose(torch.from_numpy(g["f_rest"]), e_rest, atol=1e-6)
+    assert all((got[0][k] == got[1][k]).all() for k in SHAPES)          # replicas stay bit-identical

@@ -263,3 +263,51 @@ def test_huge_gaussians_cover_many_lists(gs):
     s = {k: v[keep].contiguous() for k, v in s.items()}
     w = torch.rand(H, W, 3, generator=g)
     _vs_oracle(gs, s, (H, W, f, f * 1.1, W / 2.0 + 1.5, H / 2.0 - 2.0), torch.tensor(scenes.orbit_c2w(0, 8)), w)
+
+
+def test_factored_sh_gradient_exchange_matches_the_plain_backward(gs):
+    """dp.FactoredExchange in one process, two views: logit gradients + gsplat_sh_accumulate must give the gradients of
+    the ordinary backward summed over the views, and sh_accumulate must match the oracle's SH basis."""
+    import importlib
+    dp = importlib.import_module("3d-gaussian-splatting-for-novel-view-synthesis_amd.dp")
+    ops = importlib.import_module("3d-gaussian-splatting-for-novel-view-synthesis_amd.ops")
+    d = util.load("g1_generic")
+    rng = np.random.default_rng(9)
+    cams = [torch.tensor(d["c2w"], device=DEV), torch.tensor(scenes._camera(rng), device=DEV)]
+    ws = [torch.tensor(d["wrand"], device=DEV), torch.rand(d["H"], d["W"], 3, device=DEV)]
+    names = ("pos", "f_dc", "f_rest", "opacity_raw", "scale_raw", "q_raw")
+
+    def run(exchange):
+        p = util.tensors(d, F32, device=DEV, grad=True)
+        ex = dp.FactoredExchange(p, world_views=2) if exchange else None
+        if ex is not None:
+            ex.__enter__()
+        for c2w, w in zip(cams, ws):
+            img = gs.render_gaussians(*[p[k] for k in names], c2w, *util.cam_args(d), **d["kwargs"])
+            (img * w).sum().backward()
+        if ex is not None:
+            ex.__exit__(None, None, None)
+            assert p["f_dc"].grad is None and p["f_rest"].grad is None and len(ex.logits) == 2
+            ex.finish()
+        else:
+            dp.allreduce_gradients([p[k].grad for k in names], world_views=2)
+        return {k: p[k].grad.detach().cpu().numpy() for k in names}
+
+    plain, fact = run(False), run(True)
+    for k in names:
+        scale = np.abs(plain[k]).max()
+        assert np.abs(fact[k] - plain[k]).max() <= 2e-5 * scale, (k, np.abs(fact[k] - plain[k]).max(), scale)
+    # the accumulate kernel on its own against the oracle's basis
+    n, v = 333, 3
+    g = torch.Generator().manual_seed(4)
+    pos, eyes, logits = torch.randn(n, 3, generator=g), torch.randn(v, 3, generator=g) * 3, torch.randn(v, n, 3, generator=g)
+    logits[1, ::5] = 0.0                                 # Gaussians a view did not bin
+    g_dc, g_rest = ops.sh_accumulate(pos.to(DEV), eyes.to(DEV), logits.to(DEV), 0.5)
+    acc = torch.zeros(n, 16, 3, dtype=torch.float64)
+    for k in range(v):
+        dd = pos.double() - eyes[k].double()
+        dd = dd / (dd.norm(dim=-1, keepdim=True) + 1e-8)
+        acc += tp.sh_basis(dd).unsqueeze(-1) * logits[k].double().unsqueeze(1)
+    acc *= 0.5
+    assert (g_dc.cpu().double() - acc[:, 0, :]).abs().max() < 1e-5
+    assert (g_rest.cpu().double() - acc[:, 1:, :].transpose(1, 2).reshape(n, 45)).abs().max() < 1e-5
