@@ -171,57 +171,6 @@ int check_gaussians(const gsplat_gaussians* g, bool* fused) {
     return GSPLAT_OK;
 }
 
-// ---- device helpers ------------------------------------------------------------------------------
-
-__device__ __forceinline__ float dpp_row_sum(float v) {
-    // sum across the 64 lanes with DPP; the total ends up in lane 63 (row 3)
-    int x;
-#define DPP_ADD(ctrl, rmask)                                                                       \
-    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xF, false);               \
-    v += __int_as_float(x);
-    DPP_ADD(0xB1, 0xF)    // quad_perm [1,0,3,2]
-    DPP_ADD(0x4E, 0xF)    // quad_perm [2,3,0,1]
-    DPP_ADD(0x141, 0xF)   // row_half_mirror
-    DPP_ADD(0x140, 0xF)   // row_mirror
-    DPP_ADD(0x142, 0xA)   // row_bcast15 -> rows 1, 3
-    DPP_ADD(0x143, 0xC)   // row_bcast31 -> rows 2, 3
-#undef DPP_ADD
-    return v;
-}
-
-// Nine wave totals at once, step-interleaved so that no DPP instruction reads a register written by the previous
-// instruction (no s_nop padding between dependent VALU -> DPP pairs).
-__device__ __forceinline__ void wave_total9(float (&v)[9]) {
-#define DPP_STEP(ctrl, rmask)                                                                              \
-    _Pragma("unroll") for (int k = 0; k < 9; ++k) {                                                         \
-        const int x = __builtin_amdgcn_update_dpp(0, __float_as_int(v[k]), ctrl, rmask, 0xF, false);        \
-        v[k] += __int_as_float(x);                                                                          \
-    }
-    DPP_STEP(0xB1, 0xF)
-    DPP_STEP(0x4E, 0xF)
-    DPP_STEP(0x141, 0xF)
-    DPP_STEP(0x140, 0xF)
-    DPP_STEP(0x142, 0xA)
-    DPP_STEP(0x143, 0xC)
-#undef DPP_STEP
-#pragma unroll
-    for (int k = 0; k < 9; ++k) v[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[k]), 63));
-}
-
-__device__ __forceinline__ float wave_total(float v) {
-    v = dpp_row_sum(v);
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-
-// XCD-aware block -> tile map: blocks b, b+8, b+16, ... share an XCD (round-robin dispatch), so give each
-// XCD group one contiguous range of tile ids (contiguous tile rows => neighbouring tiles => shared L2 lines).
-// Bijective for any tile count (cdna_hip_programming.md, "XCD swizzle must be bijective").
-__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t n) {
-    const uint32_t xcd = b & 7u, q = n >> 3, r = n & 7u;
-    const uint32_t start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return start + (b >> 3);
-}
-
 // ---- K0 ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void camera_kernel(const float* __restrict__ c2w, Camera* cam, DevCounts* counts, CountShard* shards,
                                                      uint32_t* __restrict__ bin_total, int nb) {
