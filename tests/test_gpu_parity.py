@@ -311,3 +311,43 @@ def test_factored_sh_gradient_exchange_matches_the_plain_backward(gs):
     acc *= 0.5
     assert (g_dc.cpu().double() - acc[:, 0, :]).abs().max() < 1e-5
     assert (g_rest.cpu().double() - acc[:, 1:, :].transpose(1, 2).reshape(n, 45)).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_scenes_vs_oracle(gs, seed):
+    """Randomised image sizes, cameras, anisotropies and opacities against the float64 oracle: exercises ragged list grids,
+    partial coarse bins, masks of thin rotated ellipses, chunk and group boundaries of the binning and raster kernels."""
+    rng = np.random.default_rng(1000 + seed)
+    H, W = int(rng.integers(9, 150)), int(rng.integers(9, 200))
+    n = int(rng.integers(1, 1800))
+    f = float(rng.uniform(40, 160))
+    cam = (H, W, f, f * float(rng.uniform(0.9, 1.1)), W / 2 + float(rng.uniform(-5, 5)), H / 2 + float(rng.uniform(-5, 5)))
+    c2w = torch.tensor(scenes._camera(rng, tilt=0.3))
+    s = scenes._base(rng, n, H, W, cam[2], cam[3], cam[4], cam[5], mu_s=float(rng.uniform(-3.2, -1.2)), sd_s=float(rng.uniform(0.2, 1.0)),
+                     op_mu=float(rng.uniform(-2, 3)), op_sd=1.5, spread=1.3, c2w=c2w.numpy())
+    t = {k: torch.tensor(s[k]) for k in util.PARAMS}
+    # drop near depth ties (fp32 cannot order them; the reference's argsort is unstable there)
+    zc = tp.to_camera(t["pos"].double(), c2w.double())[2]
+    zs, order = torch.sort(zc)
+    keep = torch.ones(n, dtype=torch.bool)
+    keep[order[1:][(zs[1:] - zs[:-1]) < 2e-5]] = False
+    t = {k: v[keep].contiguous() for k, v in t.items()}
+    w = torch.tensor(rng.uniform(0, 1, (H, W, 3)).astype(np.float32))
+    p64 = {k: v.double().requires_grad_(True) for k, v in t.items()}
+    try:
+        ref = tp.render_fused(p64["pos"], p64["f_dc"], p64["f_rest"], p64["opacity_raw"], p64["scale_raw"], p64["q_raw"], c2w.double(), *cam)
+    except Exception as e:                                  # all off-screen: the HIP path must raise the same
+        with pytest.raises(Exception, match=str(e)):
+            gs.render_gaussians(*[t[k].to(DEV) for k in ("pos", "f_dc", "f_rest", "opacity_raw", "scale_raw", "q_raw")], c2w.to(DEV), *cam)
+        return
+    (ref * w.double()).sum().backward()
+    p = {k: v.to(DEV).requires_grad_(True) for k, v in t.items()}
+    img = gs.render_gaussians(p["pos"], p["f_dc"], p["f_rest"], p["opacity_raw"], p["scale_raw"], p["q_raw"], c2w.to(DEV), *cam)
+    (img * w.to(DEV)).sum().backward()
+    util.check_image(img.detach().cpu().numpy(), ref.detach().numpy(), frac=0.995)
+    for k in util.PARAMS:
+        g64 = p64[k].grad.numpy()
+        if np.abs(g64).max() > 0:
+            util.check_grad(p[k].grad.cpu().numpy(), g64, k)
+        else:
+            assert float(p[k].grad.abs().max()) == 0.0
