@@ -623,10 +623,12 @@ __global__ __launch_bounds__(256) void split_scatter_kernel(int nl, int nb, cons
 __device__ __forceinline__ uint32_t work_bucket(uint32_t w) {
     if (w < 8u) return w;
     const uint32_t e = 31u - (uint32_t)__clz((int)w);
-    return (e - 2u) * 8u + ((w >> (e - 3u)) & 7u);          // <= 239; 256 -> 48, 1024 -> 64, 4096 -> 80
+    return (e - 2u) * 8u + ((w >> (e - 3u)) & 7u);          // <= 239; 256 -> 48, 1024 -> 64, 4096 -> 80, 8192 -> 88
 }
-constexpr int SORT_CLASSES = 4;                               // list length >= 4096 | >= 1024 | >= 256 | >= 1
-__device__ __forceinline__ uint32_t class_first_bucket(int c) { return c == 0 ? 80u : (c == 1 ? 64u : (c == 2 ? 48u : 1u)); }
+constexpr int SORT_CLASSES = 5;                               // list length >= 8192 | >= 4096 | >= 1024 | >= 256 | >= 1
+__device__ __forceinline__ uint32_t class_first_bucket(int c) {
+    return c == 0 ? 88u : (c == 1 ? 80u : (c == 2 ? 64u : (c == 3 ? 48u : 1u)));
+}
 
 // Counting sort of the lists by work bucket, descending.  Same-address LDS atomics serialise and neighbouring lists
 // often share a bucket, so every bucket has 16 sub-counters selected by the lane (flat index = (255 - bucket) * 16 + sub:
@@ -694,7 +696,7 @@ __global__ __launch_bounds__(1024) void plan_kernel(int nl, const uint2* __restr
 // scatter gives bucket order; inside a bucket (expected occupancy <= 0.5) every element counts the smaller keys to find
 // its rank.  ~8 barriers instead of the ~70 compare-exchange rounds of a bitonic network.  A list whose depths are so
 // clustered that a bucket holds more than DENSE_BUCKET entries takes the bitonic network instead (exact, slower).
-// huge_sort_kernel (lists of 4096 and more): bitonic network in place in global memory.
+// huge_sort_kernel (lists of 8192 and more): bitonic network in place in global memory.
 //
 // Direction-free bitonic network: every merge of size k starts with a mirror step (i <-> block_end - i), followed by
 // the half-cleaner steps j = k/4 .. 1; every compare-exchange puts the smaller key at the lower index.  With virtual
@@ -829,9 +831,9 @@ __global__ __launch_bounds__(T) void list_sort_kernel(const uint32_t* __restrict
 #undef PADC
 }
 
-__global__ __launch_bounds__(256) void huge_sort_kernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ class_bounds,
-                                                        const uint2* __restrict__ ranges, uint64_t* __restrict__ vals,
-                                                        uint32_t* __restrict__ sorted_ids) {
+__global__ __launch_bounds__(1024) void huge_sort_kernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ class_bounds,
+                                                         const uint2* __restrict__ ranges, uint64_t* __restrict__ vals,
+                                                         uint32_t* __restrict__ sorted_ids) {
     if (blockIdx.x >= class_bounds[0]) return;
     const uint2 rg = ranges[order[blockIdx.x]];
     const uint32_t n = rg.y - rg.x;
@@ -839,11 +841,11 @@ __global__ __launch_bounds__(256) void huge_sort_kernel(const uint32_t* __restri
     uint64_t* g = vals + rg.x;
     uint32_t m = 2;
     while (m < n) m <<= 1;
-    bitonic_network<256>(n, m, tid, [&](uint32_t i, uint32_t l) {
+    bitonic_network<1024>(n, m, tid, [&](uint32_t i, uint32_t l) {
         const uint64_t a = g[i], b = g[l];
         if (a > b) { g[i] = b; g[l] = a; }
     });
-    for (uint32_t i = tid; i < n; i += 256) sorted_ids[rg.x + i] = (uint32_t)g[i] & ID_MASK;
+    for (uint32_t i = tid; i < n; i += 1024) sorted_ids[rg.x + i] = (uint32_t)g[i] & ID_MASK;
 }
 
 // ---- K6 / K7: rasterizer -----------------------------------------------------------------------------
@@ -1478,21 +1480,26 @@ int gsplat_bin(int64_t n, int64_t n_binned, const gsplat_view* v, const void* pr
     // F9 + F12: per-list sort by (depth, index); one launch per size class, grids bounded by what the class can hold
     uint64_t* vals = sc.vals;
     const auto cap = [&](int64_t min_len) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(nl, n_binned / min_len)); };
-    if (n_binned >= 4096) {
-        hipLaunchKernelGGL(huge_sort_kernel, dim3(cap(4096)), dim3(256), 0, st, ps.order, ps.class_bounds, ps.ranges, vals, sorted_ids);
+    if (n_binned >= 8192) {
+        hipLaunchKernelGGL(huge_sort_kernel, dim3(cap(8192)), dim3(1024), 0, st, ps.order, ps.class_bounds, ps.ranges, vals, sorted_ids);
         LAUNCH_CHECK("huge_sort_kernel");
     }
+    if (n_binned >= 4096) {
+        hipLaunchKernelGGL((list_sort_kernel<512, 16, 13>), dim3(cap(4096)), dim3(512), 0, st, ps.order, ps.class_bounds, 1, ps.ranges,
+                           vals, sorted_ids);
+        LAUNCH_CHECK("list_sort_kernel<8192>");
+    }
     if (n_binned >= 1024) {
-        hipLaunchKernelGGL((list_sort_kernel<256, 16, 12>), dim3(cap(1024)), dim3(256), 0, st, ps.order, ps.class_bounds, 1, ps.ranges,
+        hipLaunchKernelGGL((list_sort_kernel<256, 16, 12>), dim3(cap(1024)), dim3(256), 0, st, ps.order, ps.class_bounds, 2, ps.ranges,
                            vals, sorted_ids);
         LAUNCH_CHECK("list_sort_kernel<4096>");
     }
     if (n_binned >= 256) {
-        hipLaunchKernelGGL((list_sort_kernel<256, 4, 11>), dim3(cap(256)), dim3(256), 0, st, ps.order, ps.class_bounds, 2, ps.ranges,
+        hipLaunchKernelGGL((list_sort_kernel<256, 4, 11>), dim3(cap(256)), dim3(256), 0, st, ps.order, ps.class_bounds, 3, ps.ranges,
                            vals, sorted_ids);
         LAUNCH_CHECK("list_sort_kernel<1024>");
     }
-    hipLaunchKernelGGL((list_sort_kernel<64, 4, 9>), dim3(cap(1)), dim3(64), 0, st, ps.order, ps.class_bounds, 3, ps.ranges, vals,
+    hipLaunchKernelGGL((list_sort_kernel<64, 4, 9>), dim3(cap(1)), dim3(64), 0, st, ps.order, ps.class_bounds, 4, ps.ranges, vals,
                        sorted_ids);
     LAUNCH_CHECK("list_sort_kernel<256>");
     return GSPLAT_OK;

@@ -179,9 +179,11 @@ def test_seeded_scene_vs_cpu_oracle(gs, n, hw, fx, mu):
         util.check_grad(p[k].grad.cpu().numpy(), p64[k].grad.numpy(), k)
 
 
-def test_long_tile_lists_take_the_global_sort_path(gs):
-    """> 4096 Gaussians on the same tiles: the per-tile depth sort leaves LDS and sorts in global memory."""
-    n, H, W, f = 6000, 32, 48, 40.0
+@pytest.mark.parametrize("n,longest", [(6000, 4096), (11000, 8192)])
+def test_long_lists_take_the_large_sort_paths(gs, n, longest):
+    """Thousands of Gaussians on the same pixels: lists of 4096-8191 entries use the largest LDS sort class, longer ones are
+    sorted in global memory."""
+    H, W, f = 32, 48, 40.0
     g = torch.Generator().manual_seed(11)
     z = torch.rand(n, generator=g, dtype=torch.float64) * 4 + 2          # distinct depths
     zs, order = torch.sort(z)
@@ -200,7 +202,7 @@ def test_long_tile_lists_take_the_global_sort_path(gs):
     stages = {}
     ref = tp.render_fused(p64["pos"], p64["f_dc"], p64["f_rest"], p64["opacity_raw"], p64["scale_raw"], p64["q_raw"],
                           c2w.double(), *cam, stages=stages)
-    assert int((stages["tile_end"] - stages["tile_start"]).max()) > 4096
+    assert int((stages["tile_end"] - stages["tile_start"]).max()) > longest
     (ref * w.double()).sum().backward()
     p = {k: v.to(DEV).requires_grad_(True) for k, v in s.items()}
     img = gs.render_gaussians(p["pos"], p["f_dc"], p["f_rest"], p["opacity_raw"], p["scale_raw"], p["q_raw"], c2w.to(DEV), *cam)
