@@ -1,4 +1,4 @@
-// gs_body.h -- per-Gaussian thread bodies of the projection kernels (forward K1, backward K7) and of the
+// gs_body.h -- per-Gaussian thread bodies of the projection kernels (forward K1, backward K8) and of the
 // two stand-alone ops.  Shared by gsplat_kernels.hip (device) and host_math_check.cpp (host unit test).
 #pragma once
 #include "../../include/gsplat_mi355x.h"
@@ -80,7 +80,7 @@ struct RecOut {             // what K1 stores for one Gaussian
     int vis;
 };
 
-struct GradOut {            // what K7 stores for one Gaussian
+struct GradOut {            // what K8 stores for one Gaussian
     float p[3], o_raw, sr[3], qr[4], S9[9], col[3];
 };
 
@@ -143,7 +143,7 @@ GS_HD RecOut project_core(const GaussIn& in, bool fused, Coef coef, const Camera
     return project_finish(in, project_geometry(in, fused, cam, vk), fused, coef, cam);
 }
 
-// K7 core.  r9 = (g_u, g_v, g_A11, g_A12, g_A22, g_opacity, g_r, g_g, g_b) of a visible Gaussian.
+// K8 core.  r9 = (g_u, g_v, g_A11, g_A12, g_A22, g_opacity, g_r, g_g, g_b) of a visible Gaussian.
 // emit_sh(k, ch, val) receives dL/d(SH coefficient) for k = 0..15 (k = 0 -> f_dc); it is called for every (k, ch),
 // with zeros for a Gaussian that is not visible, so that every output row is written.
 // moments = true (what raster_backward_kernel accumulates): r9[0..4] = (Sx, Sy, Sxx, Sxy, Syy), the moments sum du^a dv^b dL/dq

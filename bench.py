@@ -79,7 +79,7 @@ def algorithmic_bytes(stage, N, V, P, HW):
             "raster_backward": 80 * P + 20 * HW, "project_backward": 272 * V + 236 * N}[stage]
 
 
-KERNEL_OF_STAGE = {"project": "project_kernel+scan_kernel+colour_kernel", "bin": "emit_pairs_kernel+radix_sort+list_sort_kernel",
+KERNEL_OF_STAGE = {"project": "project_kernel+bin_count_kernel+colour_kernel", "bin": "bin_scatter_kernel+split_*_kernel+list_sort_kernel",
                    "raster_forward": "raster_forward_kernel", "raster_backward": "raster_backward_kernel",
                    "project_backward": "project_backward_kernel"}
 
