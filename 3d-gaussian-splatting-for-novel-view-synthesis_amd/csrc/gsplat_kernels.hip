@@ -1350,17 +1350,40 @@ __global__ __launch_bounds__(256) void evaluate_sh_kernel(int64_t n, const float
     build_camera(m, cam);
     evaluate_sh_one(i, dc, rest, pts, cam, color);
 }
-__global__ __launch_bounds__(256) void evaluate_sh_backward_kernel(int64_t n, const float* __restrict__ dc, const float* __restrict__ rest,
-                                                                   const float* __restrict__ pts, const float* __restrict__ c2w,
-                                                                   const float* __restrict__ gcol, float* __restrict__ gdc,
-                                                                   float* __restrict__ grest, float* __restrict__ gpts) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+// Stand-alone evaluate_sh backward, row blocks staged through LDS like K8 (a lane reading and writing its own 180-byte rows
+// directly touched every cache line 45 times: 120 us against 60 us for 1 M Gaussians).
+__global__ __launch_bounds__(64) void evaluate_sh_backward_kernel(int64_t n, const float* __restrict__ dc, const float* __restrict__ rest,
+                                                                  const float* __restrict__ pts, const float* __restrict__ c2w,
+                                                                  const float* __restrict__ gcol, float* __restrict__ gdc,
+                                                                  float* __restrict__ grest, float* __restrict__ gpts) {
+    __shared__ float s_pos[64 * 3], s_gc[64 * 3], s_dc[64 * 3], s_rest[64 * 45];
+    const int lane = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * 64, i = row0 + lane;
+    stage_rows<3>(s_pos, pts, row0, n, lane);
+    stage_rows<3>(s_gc, gcol, row0, n, lane);
+    stage_rows<3>(s_dc, dc, row0, n, lane);
+    stage_rows<45>(s_rest, rest, row0, n, lane);
     float m[16];
     for (int k = 0; k < 16; ++k) m[k] = c2w[k];
     Camera cam;
     build_camera(m, cam);
-    evaluate_sh_backward_one(i, dc, rest, pts, cam, gcol, gdc, grest, gpts);
+    __syncthreads();
+    float gp[3] = {0.f, 0.f, 0.f};
+    if (i < n) {
+        const float p[3] = {s_pos[lane * 3], s_pos[lane * 3 + 1], s_pos[lane * 3 + 2]};
+        const float gc[3] = {s_gc[lane * 3], s_gc[lane * 3 + 1], s_gc[lane * 3 + 2]};
+        ShMid sm;
+        sh_basis(p, cam.eye, sm);
+        ShCoefLds coef{s_dc + lane * 3, s_rest + lane * 45};
+        float rgb[3];
+        sh_colour(sm, coef, rgb);
+        sh_colour_backward(sm, coef, rgb, gc, ShEmitLds{s_dc + lane * 3, s_rest + lane * 45}, gp);     // gradients over the coefficients
+    }
+    s_pos[lane * 3] = gp[0]; s_pos[lane * 3 + 1] = gp[1]; s_pos[lane * 3 + 2] = gp[2];                  // own slots: read above
+    __syncthreads();
+    unstage_rows<3>(gdc, s_dc, row0, n, lane);
+    unstage_rows<45>(grest, s_rest, row0, n, lane);
+    unstage_rows<3>(gpts, s_pos, row0, n, lane);
 }
 
 inline unsigned blocks256(int64_t n) { return (unsigned)((n + 255) / 256); }
@@ -1600,7 +1623,10 @@ int gsplat_evaluate_sh_backward(int64_t n, const float* f_dc, const float* f_res
     if (n == 0) return GSPLAT_OK;
     if (!f_dc || !f_rest || !points || !c2w || !grad_color || !grad_f_dc || !grad_f_rest || !grad_points)
         return fail(GSPLAT_ERR_BAD_ARG, "NULL argument");
-    hipLaunchKernelGGL(evaluate_sh_backward_kernel, dim3(blocks256(n)), dim3(256), 0, (hipStream_t)stream_, n, f_dc, f_rest, points, c2w,
+    if (!aligned16(f_dc) || !aligned16(f_rest) || !aligned16(points) || !aligned16(grad_color) || !aligned16(grad_f_dc) ||
+        !aligned16(grad_f_rest) || !aligned16(grad_points))
+        return fail(GSPLAT_ERR_BAD_ARG, "arrays must be 16-byte aligned");
+    hipLaunchKernelGGL(evaluate_sh_backward_kernel, dim3(blocks64(n)), dim3(64), 0, (hipStream_t)stream_, n, f_dc, f_rest, points, c2w,
                        grad_color, grad_f_dc, grad_f_rest, grad_points);
     LAUNCH_CHECK("evaluate_sh_backward_kernel");
     return GSPLAT_OK;
