@@ -108,3 +108,55 @@ def test_loss_goes_down_and_densification_keeps_training():
         p = getattr(model, k)
         assert p.shape[0] == counts[-1] and torch.isfinite(p).all()
     assert np.mean(losses[-5:]) < 0.8 * np.mean(losses[:5]), (losses[:5], losses[-5:])
+
+
+def _dp_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model_mod = importlib.import_module(PKG + ".model")
+    training = importlib.import_module(PKG + ".training")
+    s, views = _scene()
+    model = model_mod.GaussianModel({k: torch.tensor(s[k]) for k in NAMES}, device="cuda:0")
+    tr = training.Trainer(model, training.TrainConfig(densification_interval=2, densify_until_iter=3, max_grad=1e-4))
+    out = None
+    for it in (1, 2, 3):                     # iteration 2 densifies: the replicas must stay identical through it
+        out = tr.step(it, [views[rank]], global_views=world)
+    q.put((rank, {k: getattr(model, k).detach().cpu().numpy() for k in NAMES}, out["gaussians"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_training_matches_single_process():
+    """Two ranks (gloo, both on cuda:0), one view each, factored gradient exchange, against one process rendering both
+    views: same parameters after three iterations including a densification, and bit-identical replicas."""
+    import socket
+    import torch.multiprocessing as mp
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r, (params, n)) for r, params, n in (q.get(timeout=300) for _ in range(2)))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    model_mod = importlib.import_module(PKG + ".model")
+    training = importlib.import_module(PKG + ".training")
+    s, views = _scene()
+    model = model_mod.GaussianModel({k: torch.tensor(s[k]) for k in NAMES}, device="cuda:0")
+    tr = training.Trainer(model, training.TrainConfig(densification_interval=2, densify_until_iter=3, max_grad=1e-4))
+    for it in (1, 2, 3):
+        out = tr.step(it, views)
+    assert got[0][1] == got[1][1] == out["gaussians"]
+    for k in NAMES:
+        assert np.array_equal(got[0][0][k], got[1][0][k]), k                       # replicas bit-identical
+        ref = getattr(model, k).detach().cpu().numpy()
+        # Adam normalises: compare the movement where it is well above the fp32 noise of the gradient sums
+        err = np.abs(got[0][0][k] - ref)
+        assert np.quantile(err, 0.99) <= 1e-4 * max(1.0, np.abs(ref).max()), (k, float(np.quantile(err, 0.99)))
