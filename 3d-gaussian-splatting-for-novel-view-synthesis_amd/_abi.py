@@ -56,8 +56,8 @@ SIGNATURES = {
     "gsplat_bin_scratch_bytes": (_I64, [_I64, _PV]),
     "gsplat_project": (_INT, [_PG, _VP, _PV, _VP, _VP, _I64, _VP, _VP, _VP]),
     "gsplat_bin": (_INT, [_I64, _I64, _PV, _VP, _VP, _VP, _I64, _VP]),
-    "gsplat_rasterize_forward": (_INT, [_I64, _I64, _PV, _VP, _VP, _VP, _VP, _VP]),
-    "gsplat_rasterize_backward": (_INT, [_I64, _I64, _PV, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "gsplat_rasterize_forward": (_INT, [_I64, _I64, _PV, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "gsplat_rasterize_backward": (_INT, [_I64, _I64, _PV, _VP, _VP, _VP, _VP, _VP, C.c_int32, _VP]),
     "gsplat_project_backward": (_INT, [_PG, _VP, _PV, _VP, _VP, _PGG, _VP]),
     "gsplat_sh_accumulate": (_INT, [_I64, C.c_int32, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP]),
     "gsplat_build_sigma": (_INT, [_I64, _VP, _VP, _VP, _VP]),

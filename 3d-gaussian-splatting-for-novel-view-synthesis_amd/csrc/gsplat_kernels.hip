@@ -929,9 +929,20 @@ __global__ __launch_bounds__(64) void raster_forward_kernel(const uint2* __restr
                                                             const Rec64* __restrict__ rec, const uint32_t* __restrict__ order,
                                                             int tiles_x, int H, int W, float chi, float alpha_max,
                                                             float alpha_cutoff, float* __restrict__ image,
-                                                            float* __restrict__ accum, WaveStats* __restrict__ stats, uint32_t id_max) {
+                                                            float* __restrict__ accum, WaveStats* __restrict__ stats, uint32_t id_max,
+                                                            float* __restrict__ zero_rows, int64_t n_zero_rows) {
     __shared__ RasterStage s;
     const int lane = threadIdx.x;
+    if (zero_rows) {        // the coming backward accumulates into grad2d: clear this wave's share now (the kernel is VALU-bound,
+                            // the stores ride along; a separate 64 MB fill cost 10 us + a dependent launch)
+        const int64_t per = (n_zero_rows + gridDim.x - 1) / gridDim.x, r0 = (int64_t)blockIdx.x * per;
+        const int64_t r1 = r0 + per < n_zero_rows ? r0 + per : n_zero_rows;
+        const f4 z = f4{0.f, 0.f, 0.f, 0.f};
+        for (int64_t r = r0 + lane; r < r1; r += 64) {
+            f4* row = reinterpret_cast<f4*>(zero_rows + r * 16);
+            row[0] = z; row[1] = z; row[2] = z; row[3] = z;
+        }
+    }
     const uint32_t list = order[blockIdx.x];
     const int tx = list % tiles_x, hy = list / tiles_x;
     const int prio = launch_priority(blockIdx.x, gridDim.x);
@@ -1529,7 +1540,7 @@ int gsplat_bin(int64_t n, int64_t n_binned, const gsplat_view* v, const void* pr
 }
 
 int gsplat_rasterize_forward(int64_t n, int64_t n_binned, const gsplat_view* v, const void* project_state, const void* bin_state,
-                             float* image, float* accum, void* stream_) {
+                             float* image, float* accum, float* grad2d, void* stream_) {
     (void)n_binned;
     int rc = check_view(v);
     if (rc) return rc;
@@ -1539,13 +1550,13 @@ int gsplat_rasterize_forward(int64_t n, int64_t n_binned, const gsplat_view* v, 
     const int64_t nl = n_lists(v);
     ProjectState ps = carve_project((void*)project_state, n > 0 ? n : 1, nl);
     hipLaunchKernelGGL(raster_forward_kernel, dim3((unsigned)nl), dim3(64), 0, st, ps.ranges, (const uint32_t*)bin_state, ps.rec,
-                       ps.order, vk.tiles_x, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, image, accum, g_stats_fwd, (uint32_t)(n > 0 ? n - 1 : 0));
+                       ps.order, vk.tiles_x, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, image, accum, g_stats_fwd, (uint32_t)(n > 0 ? n - 1 : 0), grad2d, grad2d ? n : 0);
     LAUNCH_CHECK("raster_forward_kernel");
     return GSPLAT_OK;
 }
 
 int gsplat_rasterize_backward(int64_t n, int64_t n_binned, const gsplat_view* v, const void* project_state, const void* bin_state,
-                              const float* accum, const float* grad_image, float* grad2d, void* stream_) {
+                              const float* accum, const float* grad_image, float* grad2d, int32_t grad2d_zeroed, void* stream_) {
     int rc = check_view(v);
     if (rc) return rc;
     if (!project_state || !bin_state || !accum || !grad_image || !grad2d) return fail(GSPLAT_ERR_BAD_ARG, "NULL argument");
@@ -1553,7 +1564,7 @@ int gsplat_rasterize_backward(int64_t n, int64_t n_binned, const gsplat_view* v,
     const ViewK vk = make_viewk(*v);
     const int64_t nl = n_lists(v);
     ProjectState ps = carve_project((void*)project_state, n > 0 ? n : 1, nl);
-    HIP_TRY(hipMemsetAsync(grad2d, 0, (size_t)(n > 0 ? n : 0) * 16 * sizeof(float), st));
+    if (!grad2d_zeroed) HIP_TRY(hipMemsetAsync(grad2d, 0, (size_t)(n > 0 ? n : 0) * 16 * sizeof(float), st));
     if (n == 0 || n_binned == 0) return GSPLAT_OK;
     hipLaunchKernelGGL(raster_backward_kernel, dim3((unsigned)nl), dim3(64), 0, st, ps.ranges, (const uint32_t*)bin_state, ps.rec,
                        ps.order, vk.tiles_x, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, accum, grad_image,

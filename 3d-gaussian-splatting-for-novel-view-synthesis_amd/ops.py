@@ -140,7 +140,7 @@ def _make_gaussians(n, pos, opacity_raw, color=None, sigma=None, scale_raw=None,
 
 class _Frame:
     """Everything the backward pass needs from one forward call."""
-    __slots__ = ("view", "n", "n_pairs", "proj_state", "bin_state", "accum", "fused", "inputs", "c2w", "empty")
+    __slots__ = ("view", "n", "n_pairs", "proj_state", "bin_state", "accum", "fused", "inputs", "c2w", "empty", "grad2d")
 
 
 def _forward_impl(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad):
@@ -195,9 +195,13 @@ def _forward_impl(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad):
             _abi.check(lib.gsplat_bin(n, fr.n_pairs, C.byref(view), _p(fr.proj_state), _p(fr.bin_state), _p(scratch),
                                       scratch.numel(), st), "gsplat_bin")
         fr.accum = torch.empty((H, W, 3), dtype=torch.float32, device=dev) if need_grad else None
+        # the forward rasterizer clears the backward's accumulation buffer on the side (its waves are VALU-bound), unless
+        # there are so few lists that a wave's share would be long
+        lists = ((W + 15) // 16) * ((H + 7) // 8)
+        fr.grad2d = torch.empty((n, 16), dtype=torch.float32, device=dev) if need_grad and n <= 256 * lists else None
         with _stage("raster_forward"):
             _abi.check(lib.gsplat_rasterize_forward(n, fr.n_pairs, C.byref(view), _p(fr.proj_state), _p(fr.bin_state),
-                                                    _p(image), _p(fr.accum), st), "gsplat_rasterize_forward")
+                                                    _p(image), _p(fr.accum), _p(fr.grad2d), st), "gsplat_rasterize_forward")
     return image, fr, counts
 
 
@@ -239,10 +243,12 @@ def _backward_impl(fr, grad_image):
     gi = _f32(grad_image, (fr.view.H, fr.view.W, 3), "grad_image")
     st = _stream_ptr(dev)
     with torch.cuda.device(dev):
-        grad2d = torch.empty((fr.n, 16), dtype=torch.float32, device=dev)
+        zeroed = fr.grad2d is not None
+        grad2d = fr.grad2d if zeroed else torch.empty((fr.n, 16), dtype=torch.float32, device=dev)
+        fr.grad2d = None                       # a second backward through the same graph must not reuse a dirty buffer
         with _stage("raster_backward"):
             _abi.check(lib.gsplat_rasterize_backward(fr.n, fr.n_pairs, C.byref(fr.view), _p(fr.proj_state), _p(fr.bin_state),
-                                                     _p(fr.accum), _p(gi), _p(grad2d), st), "gsplat_rasterize_backward")
+                                                     _p(fr.accum), _p(gi), _p(grad2d), int(zeroed), st), "gsplat_rasterize_backward")
         out = _flat_like({k: v for k, v in ins.items() if not (factored and k in ("f_dc", "f_rest"))})
         glogit = torch.empty((fr.n, 3), dtype=torch.float32, device=dev) if factored else None
         g = _make_gaussians(fr.n, **ins)

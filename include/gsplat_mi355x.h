@@ -133,17 +133,20 @@ int gsplat_bin(int64_t n, int64_t n_binned, const gsplat_view* v, const void* pr
                void* scratch, int64_t scratch_bytes, void* stream);
 
 /* F14, F15: per-tile front-to-back compositing.  image[H,W,3] receives clamp(C,0,1); accum[H,W,3]
- * (nullable; required for the backward pass) receives the unclamped C.                                */
+ * (nullable; required for the backward pass) receives the unclamped C.  grad2d (nullable, [n,16]
+ * floats): cleared here for the coming gsplat_rasterize_backward (pass grad2d_zeroed = 1 there), which
+ * saves that call a 64-byte-per-Gaussian fill; only worth it when n / lists is small (<= 256).          */
 int gsplat_rasterize_forward(int64_t n, int64_t n_binned, const gsplat_view* v, const void* project_state,
-                             const void* bin_state, float* image, float* accum, void* stream);
+                             const void* bin_state, float* image, float* accum, float* grad2d, void* stream);
 
 /* ---- backward ---------------------------------------------------------------------------------- */
 /* B1: gradient of the compositing w.r.t. the per-Gaussian 2D quantities.  grad2d is [n,16] floats, private to the
  * library (moments of dL/dq over the pixels for the centre and the conic, then opacity, r, g, b, padding); it is zeroed
- * by this call before accumulation and consumed by gsplat_project_backward.                                          */
+ * by this call before accumulation (unless grad2d_zeroed: gsplat_rasterize_forward already cleared it) and consumed
+ * by gsplat_project_backward.                                                                                        */
 int gsplat_rasterize_backward(int64_t n, int64_t n_binned, const gsplat_view* v, const void* project_state,
                               const void* bin_state, const float* accum, const float* grad_image,
-                              float* grad2d, void* stream);
+                              float* grad2d, int32_t grad2d_zeroed, void* stream);
 
 /* B2 (+B3 when fused): chain the 2D gradients back to the inputs of gsplat_project.
  * Factored form (fused inputs; out->f_dc and out->f_rest NULL, out->color given): instead of the 48 SH-coefficient
