@@ -5,8 +5,8 @@
 //   K1  project_kernel         per Gaussian: culls, EWA, eigen clamp, conic, rectangles         [F1-F8, F10, F13]
 //   K1b colour_kernel          SH colour of the binned Gaussians (fused inputs)                 [F3]
 //   K2  finish_counts_kernel   totals of the sharded counters -> gsplat_counts
-//   K3  bin_count / bin_scatter / bin_local_kernel   two-level counting sort of the (list, Gaussian) pairs by list  [F11, F12]
-//   K4  list_sort_kernel       per-list depth sort in LDS (huge_sort_kernel: in global memory)  [F9, F12]
+//   K3  bin_count / bin_scatter / split_count / split_scatter_kernel   two-level counting sort of the pairs by list  [F11, F12]
+//   K4  list_sort_kernel       per-list depth sort in LDS (lists of 8192+: in global memory)    [F9, F12]
 //   K5  plan_kernel            longest-first launch order of the lists, sort size classes
 //   K6  raster_forward_kernel  one wave64 per 16x8 half tile = list, 2 pixels per lane          [F14, F15]
 //   K7  raster_backward_kernel same traversal, analytic gradients, 63-value reduce-scatter      [B1]
@@ -65,7 +65,7 @@ struct alignas(64) CountShard { int32_t survivors, visible, max_tiles; uint32_t 
 // A "list" is the depth-ordered set of Gaussians of one HALF tile (16 x 8 pixels): the unit one wave64 rasterises.
 // Binning is a two-level counting sort: (list, Gaussian) pairs go to coarse bins of 64 consecutive lists first
 // (bin_count_kernel / bin_scatter_kernel, blocks of 2048 Gaussians with an LDS histogram, one global atomic per block and
-// bin), then every bin is split into its 64 lists in LDS (bin_local_kernel), then every list is sorted by depth.
+// bin), then every bin is split into its 64 lists (split_count_kernel / split_scatter_kernel), then every list is sorted by depth.
 constexpr int BIN_SHIFT = 6;                 // 64 lists per coarse bin
 constexpr int BIN_GAUSS = 2048;              // Gaussians per block of bin_count_kernel / bin_scatter_kernel
 constexpr int MAX_BINS = 8192;               // LDS histogram of the two kernels (32 KB): images up to 8192 x 8192 / 128 lists
@@ -625,10 +625,8 @@ __device__ __forceinline__ uint32_t work_bucket(uint32_t w) {
     const uint32_t e = 31u - (uint32_t)__clz((int)w);
     return (e - 2u) * 8u + ((w >> (e - 3u)) & 7u);          // <= 239; 256 -> 48, 1024 -> 64, 4096 -> 80, 8192 -> 88
 }
-constexpr int SORT_CLASSES = 5;                               // list length >= 8192 | >= 4096 | >= 1024 | >= 256 | >= 1
-__device__ __forceinline__ uint32_t class_first_bucket(int c) {
-    return c == 0 ? 88u : (c == 1 ? 80u : (c == 2 ? 64u : (c == 3 ? 48u : 1u)));
-}
+constexpr int SORT_CLASSES = 3;                               // list length >= 1024 | >= 256 | >= 1
+__device__ __forceinline__ uint32_t class_first_bucket(int c) { return c == 0 ? 64u : (c == 1 ? 48u : 1u); }
 
 // Counting sort of the lists by work bucket, descending.  Same-address LDS atomics serialise and neighbouring lists
 // often share a bucket, so every bucket has 16 sub-counters selected by the lane (flat index = (255 - bucket) * 16 + sub:
@@ -696,7 +694,7 @@ __global__ __launch_bounds__(1024) void plan_kernel(int nl, const uint2* __restr
 // scatter gives bucket order; inside a bucket (expected occupancy <= 0.5) every element counts the smaller keys to find
 // its rank.  ~8 barriers instead of the ~70 compare-exchange rounds of a bitonic network.  A list whose depths are so
 // clustered that a bucket holds more than DENSE_BUCKET entries takes the bitonic network instead (exact, slower).
-// huge_sort_kernel (lists of 8192 and more): bitonic network in place in global memory.
+// Lists of 8192 and more (longer than the largest LDS class holds): the same bitonic network in place in global memory.
 //
 // Direction-free bitonic network: every merge of size k starts with a mirror step (i <-> block_end - i), followed by
 // the half-cleaner steps j = k/4 .. 1; every compare-exchange puts the smaller key at the lower index.  With virtual
@@ -727,7 +725,7 @@ constexpr uint32_t DENSE_BUCKET = 48;
 
 template <int T, int E, int LOG2B>
 __global__ __launch_bounds__(T) void list_sort_kernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ class_bounds,
-                                                      int cls, const uint2* __restrict__ ranges, const uint64_t* __restrict__ vals,
+                                                      int cls, const uint2* __restrict__ ranges, uint64_t* __restrict__ vals,
                                                       uint32_t* __restrict__ sorted_ids) {
     constexpr int CAP = T * E, B = 1 << LOG2B, CPT = B / T;       // CPT counters per thread in the scan
     static_assert((CPT & (CPT - 1)) == 0 && CPT >= 2, "B / T must be a power of two");
@@ -735,13 +733,23 @@ __global__ __launch_bounds__(T) void list_sort_kernel(const uint32_t* __restrict
     __shared__ uint64_t sk[CAP];
     __shared__ uint32_t cnt[B + T];                               // padded: counter c lives at c + c / CPT (conflict-free scan)
     __shared__ uint32_t red[4 + T / 64];
-    const uint32_t lo = class_bounds[cls - 1], hi = class_bounds[cls];
+    const uint32_t lo = cls ? class_bounds[cls - 1] : 0u, hi = class_bounds[cls];
     if (lo + blockIdx.x >= hi) return;
     const int tid = threadIdx.x;
     const uint2 rg = ranges[order[lo + blockIdx.x]];
-    const uint32_t n = rg.y - rg.x;                               // 1 <= n < CAP by the class bounds
-    const uint64_t* __restrict__ g = vals + rg.x;
+    const uint32_t n = rg.y - rg.x;                               // 1 <= n; n < CAP by the class bounds, except in class 0
+    uint64_t* __restrict__ g = vals + rg.x;
     uint32_t* __restrict__ out = sorted_ids + rg.x;
+    if (n >= (uint32_t)CAP) {                                     // class 0 only: longer than the LDS holds -> in place in global memory
+        uint32_t m = 2;
+        while (m < n) m <<= 1;
+        bitonic_network<T>(n, m, tid, [&](uint32_t i, uint32_t l) {
+            const uint64_t a = g[i], b = g[l];
+            if (a > b) { g[i] = b; g[l] = a; }
+        });
+        for (uint32_t i = tid; i < n; i += T) out[i] = (uint32_t)g[i] & ID_MASK;
+        return;
+    }
 #define PADC(c) ((c) + ((c) >> LOG2CPT))
     uint64_t key[E];
     uint32_t mn = 0xFFFFFFFFu, mx = 0u;
@@ -829,23 +837,6 @@ __global__ __launch_bounds__(T) void list_sort_kernel(const uint32_t* __restrict
         }
     }
 #undef PADC
-}
-
-__global__ __launch_bounds__(1024) void huge_sort_kernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ class_bounds,
-                                                         const uint2* __restrict__ ranges, uint64_t* __restrict__ vals,
-                                                         uint32_t* __restrict__ sorted_ids) {
-    if (blockIdx.x >= class_bounds[0]) return;
-    const uint2 rg = ranges[order[blockIdx.x]];
-    const uint32_t n = rg.y - rg.x;
-    const int tid = threadIdx.x;
-    uint64_t* g = vals + rg.x;
-    uint32_t m = 2;
-    while (m < n) m <<= 1;
-    bitonic_network<1024>(n, m, tid, [&](uint32_t i, uint32_t l) {
-        const uint64_t a = g[i], b = g[l];
-        if (a > b) { g[i] = b; g[l] = a; }
-    });
-    for (uint32_t i = tid; i < n; i += 1024) sorted_ids[rg.x + i] = (uint32_t)g[i] & ID_MASK;
 }
 
 // ---- K6 / K7: rasterizer -----------------------------------------------------------------------------
@@ -1514,26 +1505,17 @@ int gsplat_bin(int64_t n, int64_t n_binned, const gsplat_view* v, const void* pr
     // F9 + F12: per-list sort by (depth, index); one launch per size class, grids bounded by what the class can hold
     uint64_t* vals = sc.vals;
     const auto cap = [&](int64_t min_len) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(nl, n_binned / min_len)); };
-    if (n_binned >= 8192) {
-        hipLaunchKernelGGL(huge_sort_kernel, dim3(cap(8192)), dim3(1024), 0, st, ps.order, ps.class_bounds, ps.ranges, vals, sorted_ids);
-        LAUNCH_CHECK("huge_sort_kernel");
-    }
-    if (n_binned >= 4096) {
-        hipLaunchKernelGGL((list_sort_kernel<512, 16, 13>), dim3(cap(4096)), dim3(512), 0, st, ps.order, ps.class_bounds, 1, ps.ranges,
+    if (n_binned >= 1024) {       // lists of 1024+ entries: 100 KB of LDS per workgroup; 8192+ fall back to global memory inside
+        hipLaunchKernelGGL((list_sort_kernel<512, 16, 13>), dim3(cap(1024)), dim3(512), 0, st, ps.order, ps.class_bounds, 0, ps.ranges,
                            vals, sorted_ids);
         LAUNCH_CHECK("list_sort_kernel<8192>");
     }
-    if (n_binned >= 1024) {
-        hipLaunchKernelGGL((list_sort_kernel<256, 16, 12>), dim3(cap(1024)), dim3(256), 0, st, ps.order, ps.class_bounds, 2, ps.ranges,
-                           vals, sorted_ids);
-        LAUNCH_CHECK("list_sort_kernel<4096>");
-    }
     if (n_binned >= 256) {
-        hipLaunchKernelGGL((list_sort_kernel<256, 4, 11>), dim3(cap(256)), dim3(256), 0, st, ps.order, ps.class_bounds, 3, ps.ranges,
+        hipLaunchKernelGGL((list_sort_kernel<256, 4, 11>), dim3(cap(256)), dim3(256), 0, st, ps.order, ps.class_bounds, 1, ps.ranges,
                            vals, sorted_ids);
         LAUNCH_CHECK("list_sort_kernel<1024>");
     }
-    hipLaunchKernelGGL((list_sort_kernel<64, 4, 9>), dim3(cap(1)), dim3(64), 0, st, ps.order, ps.class_bounds, 4, ps.ranges, vals,
+    hipLaunchKernelGGL((list_sort_kernel<64, 4, 9>), dim3(cap(1)), dim3(64), 0, st, ps.order, ps.class_bounds, 2, ps.ranges, vals,
                        sorted_ids);
     LAUNCH_CHECK("list_sort_kernel<256>");
     return GSPLAT_OK;
