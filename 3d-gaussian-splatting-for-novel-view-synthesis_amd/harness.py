@@ -120,6 +120,22 @@ def benchmark_orbit(params, c2ws, H, W, fx, fy, cx, cy, fused=True, on_frame=Non
             "fps_min": fps.min(), "fps_max": fps.max(), "times": t}
 
 
+def throughput_orbit(params, c2ws, H, W, fx, fy, cx, cy, on_frame=None):
+    """Frames per second over a trajectory when frames need not be timed one by one: ops.render_frames pipelines them over
+    two streams (frame k + 1's projection / binning overlaps frame k's rasterisation).  Not the reference's protocol
+    (benchmark_orbit is): a serving-style number."""
+    dev = params["pos"].device
+    args = (params["pos"], params["f_dc"], params["f_rest"], params["opacity_raw"], params["scale_raw"], params["q_raw"])
+    cams = [torch.as_tensor(np.asarray(c), dtype=torch.float32, device=dev) for c in c2ws]
+    ops.render_frames(*args, cams[:2], H, W, fx, fy, cx, cy, on_frame=lambda k, im: None)       # warm-up
+    torch.cuda.synchronize(dev)
+    t0 = time.time()
+    ops.render_frames(*args, cams, H, W, fx, fy, cx, cy, on_frame=on_frame or (lambda k, im: None))
+    torch.cuda.synchronize(dev)
+    dt = time.time() - t0
+    return {"frames": len(cams), "seconds": dt, "fps": len(cams) / dt if dt > 0 else float("inf")}
+
+
 def format_report(stats, H, W, n_gaussians, scale_factor=1.0):
     """The metrics block scripts/render_trained.py:361-381 prints."""
     bar = "=" * 60

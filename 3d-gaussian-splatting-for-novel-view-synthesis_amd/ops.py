@@ -49,16 +49,21 @@ def _f32(t, shape, name):
 
 
 class _Workspace:
-    """Grow-only scratch buffers and one pinned counter block per device (scratch is dead after each call)."""
+    """Grow-only scratch buffers, one pinned counter block and one event per (device, stream): calls on different streams
+    never share them (scratch is dead after each call, in stream order)."""
 
     def __init__(self):
         self.scratch = {}
         self.pinned = {}
         self.events = {}
 
+    @staticmethod
+    def _key(device):
+        return (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+
     def get_event(self, device):
-        """One reusable event per device: gsplat_project records it right behind the copy of the counters."""
-        key = (device.type, device.index)
+        """One reusable event per stream: gsplat_project records it right behind the copy of the counters."""
+        key = self._key(device)
         ev = self.events.get(key)
         if ev is None:
             ev = torch.cuda.Event(enable_timing=False, blocking=False)
@@ -67,7 +72,7 @@ class _Workspace:
         return ev
 
     def get_scratch(self, device, nbytes):
-        key = (device.type, device.index)
+        key = self._key(device)
         buf = self.scratch.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
@@ -75,7 +80,7 @@ class _Workspace:
         return buf
 
     def get_pinned(self, device):
-        key = (device.type, device.index)
+        key = self._key(device)
         buf = self.pinned.get(key)
         if buf is None:
             buf = torch.zeros(C.sizeof(_abi.Counts), dtype=torch.uint8).pin_memory()
@@ -143,7 +148,14 @@ class _Frame:
     __slots__ = ("view", "n", "n_pairs", "proj_state", "bin_state", "accum", "fused", "inputs", "c2w", "empty", "grad2d")
 
 
-def _forward_impl(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad):
+class _Pending:
+    """A forward call between its two halves: projection queued, counters not read yet."""
+    __slots__ = ("frame", "gaussians", "pinned", "ready", "device", "stream")
+
+
+def _forward_begin(fused, view, c2w, pos, opacity_raw, a, b, c, d):
+    """First half of the forward pass: everything up to (not including) the host's wait for the counters.  Returns
+    (pending, None), or (None, result) when there is nothing to wait for (zero Gaussians)."""
     lib = _abi.lib()
     dev = pos.device
     n = pos.shape[0]
@@ -156,29 +168,41 @@ def _forward_impl(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad):
     else:
         ins = dict(color=_f32(a, (n, 3), "color"), sigma=_f32(b, (n, 3, 3), "sigma"))
     g = _make_gaussians(n, pos32, opa32, **ins)
-    st = _stream_ptr(dev)
     fr = _Frame()
     fr.view, fr.n, fr.fused, fr.c2w, fr.empty = view, n, fused, c2w32, False
     fr.inputs = dict(pos=pos32, opacity_raw=opa32, **ins)
-    H, W = view.H, view.W
     if n == 0:      # nothing survives by construction: the reference returns the zero image (render.py:109-112)
         fr.empty, fr.proj_state = True, None
-        return torch.zeros((H, W, 3), dtype=torch.float32, device=dev), fr, _abi.Counts(0, 0, 0, 0, 0, 0)
+        return None, (torch.zeros((view.H, view.W, 3), dtype=torch.float32, device=dev), fr, _abi.Counts(0, 0, 0, 0, 0, 0))
+    pend = _Pending()
+    pend.frame, pend.gaussians, pend.device = fr, g, dev
     with torch.cuda.device(dev):
+        pend.stream = torch.cuda.current_stream(dev)
         fr.proj_state = torch.empty(lib.gsplat_project_state_bytes(n, C.byref(view)), dtype=torch.uint8, device=dev)
-        sbytes = lib.gsplat_project_scratch_bytes(n)
-        scratch = _ws.get_scratch(dev, sbytes)
-        pinned = _ws.get_pinned(dev)
-        ready = _ws.get_event(dev)
+        scratch = _ws.get_scratch(dev, lib.gsplat_project_scratch_bytes(n))
+        pend.pinned = _ws.get_pinned(dev)
+        pend.ready = _ws.get_event(dev)
         with _stage("project"):
             _abi.check(lib.gsplat_project(C.byref(g), _p(c2w32), C.byref(view), _p(fr.proj_state), _p(scratch),
-                                          scratch.numel(), C.c_void_p(pinned.data_ptr()), C.c_void_p(ready.cuda_event), st),
-                       "gsplat_project")
+                                          scratch.numel(), C.c_void_p(pend.pinned.data_ptr()), C.c_void_p(pend.ready.cuda_event),
+                                          _stream_ptr(dev)), "gsplat_project")
+    return pend, None
+
+
+def _forward_end(pend, need_grad):
+    """Second half: wait for the counters, size the pair buffers, bin, rasterise.  Must run with the same current stream
+    as the first half."""
+    lib = _abi.lib()
+    fr, dev = pend.frame, pend.device
+    view, n = fr.view, fr.n
+    H, W = view.H, view.W
+    with torch.cuda.device(dev):
+        st = _stream_ptr(dev)
         # the one host wait of the forward pass: the pair count sizes the binning buffers, and the reference's empty /
-        # off-screen conventions need the survivor counts.  Only the counters are waited for: with fused inputs the SH
-        # colour pass is queued behind them and runs during this round trip.
-        ready.synchronize()
-        counts = _abi.Counts.from_buffer_copy(pinned.numpy().tobytes())
+        # off-screen conventions need the survivor counts.  Only the counters are waited for: the first binning kernel and
+        # (fused inputs) the SH colour pass are queued behind them and run during this round trip.
+        pend.ready.synchronize()
+        counts = _abi.Counts.from_buffer_copy(pend.pinned.numpy().tobytes())
         scene = lib.gsplat_classify_counts(C.byref(counts))
         if scene == _abi.GSPLAT_SCENE_ALL_OFFSCREEN:
             raise Exception(OFFSCREEN_MSG)
@@ -189,8 +213,7 @@ def _forward_impl(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad):
             return image.zero_(), fr, counts
         fr.n_pairs = int(counts.n_binned)            # pairs actually binned (half-tile lists); counts.n_pairs = the reference's P
         fr.bin_state = torch.empty(lib.gsplat_bin_state_bytes(fr.n_pairs, C.byref(view)), dtype=torch.uint8, device=dev)
-        sbytes = lib.gsplat_bin_scratch_bytes(fr.n_pairs, C.byref(view))
-        scratch = _ws.get_scratch(dev, sbytes)
+        scratch = _ws.get_scratch(dev, lib.gsplat_bin_scratch_bytes(fr.n_pairs, C.byref(view)))
         with _stage("bin"):
             _abi.check(lib.gsplat_bin(n, fr.n_pairs, C.byref(view), _p(fr.proj_state), _p(fr.bin_state), _p(scratch),
                                       scratch.numel(), st), "gsplat_bin")
@@ -203,6 +226,11 @@ def _forward_impl(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad):
             _abi.check(lib.gsplat_rasterize_forward(n, fr.n_pairs, C.byref(view), _p(fr.proj_state), _p(fr.bin_state),
                                                     _p(image), _p(fr.accum), _p(fr.grad2d), st), "gsplat_rasterize_forward")
     return image, fr, counts
+
+
+def _forward_impl(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad):
+    pend, done = _forward_begin(fused, view, c2w, pos, opacity_raw, a, b, c, d)
+    return done if pend is None else _forward_end(pend, need_grad)
 
 
 def _flat_like(ins):
@@ -339,6 +367,57 @@ def render_gaussians(pos, f_dc, f_rest, opacity_raw, scale_raw, q_raw, c2w, H, W
     q_raw), c2w, ...) in one pass (the reference's three-call sequence, scripts/train.py:463,502,505-508)."""
     view = _view(H, W, fx, fy, cx, cy, near, far, pix_guard, T, min_conis, chi_square_clip, alpha_max, alpha_cutoff)
     return _RenderFn.apply(True, view, c2w, pos, opacity_raw, scale_raw, q_raw, f_dc, f_rest)
+
+
+@torch.no_grad()
+def render_frames(pos, f_dc, f_rest, opacity_raw, scale_raw, q_raw, c2ws, H, W, fx, fy, cx, cy, near=0.01, far=100.0,
+                  pix_guard=32, T=16, min_conis=1e-6, chi_square_clip=6.25, alpha_max=0.99, alpha_cutoff=1 / 128., on_frame=None):
+    """Forward-only rendering of a sequence of camera poses with the frames software-pipelined over two HIP streams:
+    frame k + 1's projection / binning front (latency- and bandwidth-bound) overlaps frame k's rasterisation (VALU-bound).
+    Same images as render_gaussians() frame by frame.  Returns the list of images (or calls on_frame(k, image) and returns
+    None); the caller's current stream waits for all of them."""
+    view = _view(H, W, fx, fy, cx, cy, near, far, pix_guard, T, min_conis, chi_square_clip, alpha_max, alpha_cutoff)
+    dev = pos.device
+    main = torch.cuda.current_stream(dev)
+    streams = _pipeline_streams(dev)
+    for st in streams:
+        st.wait_stream(main)                                   # parameters produced on the caller's stream
+    cams = [torch.as_tensor(c, dtype=torch.float32, device=dev) if not isinstance(c, torch.Tensor) else c for c in c2ws]
+
+    def begin(k):
+        with torch.cuda.stream(streams[k % 2]):
+            return _forward_begin(True, view, cams[k], pos, opacity_raw, scale_raw, q_raw, f_dc, f_rest)
+
+    def end(k, started):
+        pend, done = started
+        with torch.cuda.stream(streams[k % 2]):
+            image = (done if pend is None else _forward_end(pend, False))[0]
+        return image
+
+    images = []
+    started = begin(0) if cams else None
+    for k in range(len(cams)):
+        nxt = begin(k + 1) if k + 1 < len(cams) else None      # queue the next frame's front before waiting for this one's counters
+        image = end(k, started)
+        started = nxt
+        if on_frame is not None:
+            on_frame(k, image)
+        else:
+            images.append(image)
+    for st in streams:
+        main.wait_stream(st)
+    return None if on_frame is not None else images
+
+
+_pipe_streams = {}
+
+
+def _pipeline_streams(dev):
+    key = (dev.type, dev.index)
+    got = _pipe_streams.get(key)
+    if got is None:
+        got = _pipe_streams[key] = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+    return got
 
 
 _last_counts = None

@@ -353,3 +353,27 @@ def test_random_scenes_vs_oracle(gs, seed):
             util.check_grad(p[k].grad.cpu().numpy(), g64, k)
         else:
             assert float(p[k].grad.abs().max()) == 0.0
+
+
+def test_render_frames_is_the_frame_by_frame_result(gs):
+    """The two-stream software pipeline of render_frames must return exactly the images of render_gaussians."""
+    d = util.load("g1_generic")
+    rng = np.random.default_rng(17)
+    p = util.tensors(d, F32, device=DEV)
+    names = ("pos", "f_dc", "f_rest", "opacity_raw", "scale_raw", "q_raw")
+    cams = [torch.tensor(d["c2w"], device=DEV)] + [torch.tensor(scenes._camera(rng), device=DEV) for _ in range(6)]
+    behind = np.eye(4, dtype=np.float32)
+    behind[2, 3] = 50.0                                   # camera beyond the scene: everything culled -> zero image
+    cams.insert(3, torch.tensor(behind, device=DEV))
+    with torch.no_grad():
+        ref = [gs.render_gaussians(*[p[k] for k in names], c, *util.cam_args(d), **d["kwargs"]) for c in cams]
+        got = gs.render_frames(*[p[k] for k in names], cams, *util.cam_args(d), **d["kwargs"])
+        seen = []
+        assert gs.render_frames(*[p[k] for k in names], cams, *util.cam_args(d), **d["kwargs"],
+                                on_frame=lambda k, im: seen.append((k, im.clone()))) is None
+    torch.cuda.synchronize()
+    assert len(got) == len(ref) == len(seen) and [k for k, _ in seen] == list(range(len(cams)))
+    assert float(ref[3].abs().max()) == 0.0
+    for a, b, (_, c) in zip(ref, got, seen):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    assert gs.render_frames(*[p[k] for k in names], [], *util.cam_args(d)) == []
