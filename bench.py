@@ -303,7 +303,9 @@ def main():
             "fps": world * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(KERNEL_OF_STAGE[dom]), "kernel": KERNEL_OF_STAGE[dom],
-                         "avg_launch_ms": per_stage[dom]["avg_ms"], "alg_bytes_per_launch": per_stage[dom]["alg_bytes"]},
+                         "avg_launch_ms": per_stage[dom]["avg_ms"], "alg_bytes_per_launch": per_stage[dom]["alg_bytes"],
+                         "note": "the raster kernels are VALU-bound, not HBM-bound: SQ_ACTIVE_INST_VALU busy 87 % (forward) / 98 % "
+                                 "(backward) of the kernel's cycles, profiles/r01_v14_sq_counters.txt; DESIGN.md section 6"},
             "pipeline_roofline": {"alg_bytes_per_step": alg_total, "achieved": alg_total / (ms * 1e-3) / 1e9,
                                   "frac": alg_total / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s"},
             "stages": per_stage,
