@@ -138,10 +138,11 @@ class FactoredExchange:
 
     SMALL = ("pos", "opacity_raw", "scale_raw", "q_raw")
 
-    def __init__(self, params, world_views, group=None, accumulate=None):
+    def __init__(self, params, world_views, group=None, accumulate=None, force_collectives=False):
         self.params, self.world_views, self.group = params, world_views, group
         self.logits, self.eyes = [], []
         self._accumulate = accumulate
+        self._force = force_collectives          # tests: issue the collectives even in a one-rank group
 
     def add(self, grad_logit, eye):
         self.logits.append(grad_logit)
@@ -164,7 +165,7 @@ class FactoredExchange:
             if p[k].grad is None:
                 p[k].grad = torch.zeros_like(p[k])
             small.append(p[k].grad)
-        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        distributed = dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self._force)
         n = p["pos"].shape[0]
         if self.logits:
             logits, eyes = torch.stack(self.logits), torch.stack(self.eyes)

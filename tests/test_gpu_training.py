@@ -160,3 +160,54 @@ def test_data_parallel_training_matches_single_process():
         # Adam normalises: compare the movement where it is well above the fp32 noise of the gradient sums
         err = np.abs(got[0][0][k] - ref)
         assert np.quantile(err, 0.99) <= 1e-4 * max(1.0, np.abs(ref).max()), (k, float(np.quantile(err, 0.99)))
+
+
+def _rccl_worker(port, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    gs = importlib.import_module(PKG)
+    dp = importlib.import_module(PKG + ".dp")
+    s, views = _scene()
+    res = {}
+    for mode in ("plain", "factored"):
+        p = {k: torch.tensor(s[k], device="cuda:0").requires_grad_(True) for k in NAMES}
+        ex = dp.FactoredExchange(p, world_views=2, force_collectives=True) if mode == "factored" else None
+        if ex is not None:
+            ex.__enter__()
+        for v in views:
+            img = gs.render_gaussians(*[p[k] for k in ("pos", "f_dc", "f_rest", "opacity_raw", "scale_raw", "q_raw")],
+                                      torch.tensor(v["c2w"], device="cuda:0"), v["H"], v["W"], v["fx"], v["fy"], v["cx"], v["cy"])
+            (img * torch.tensor(v["image"], device="cuda:0")).sum().backward()
+        if ex is not None:
+            ex.__exit__(None, None, None)
+            ex.finish()                                   # all_reduce + all_gather_into_tensor over RCCL (one rank)
+        else:
+            dp.allreduce_gradients([p[k].grad for k in NAMES], world_views=2)
+        res[mode] = {k: p[k].grad.cpu().numpy() for k in NAMES}
+    q.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_collectives_run_over_rccl():
+    """The collectives of the data-parallel exchange through the real RCCL backend (a one-rank group is what a one-GPU box
+    allows): same gradients as the plain path."""
+    import socket
+    import torch.multiprocessing as mp
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    proc = ctx.Process(target=_rccl_worker, args=(port, q))
+    proc.start()
+    res = q.get(timeout=300)
+    proc.join(timeout=120)
+    assert proc.exitcode == 0
+    for k in NAMES:
+        scale = np.abs(res["plain"][k]).max()
+        assert np.abs(res["factored"][k] - res["plain"][k]).max() <= 2e-5 * scale, k
