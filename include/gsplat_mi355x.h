@@ -115,19 +115,21 @@ int64_t gsplat_bin_scratch_bytes(int64_t n_binned, const gsplat_view* v); /* fre
 
 /* ---- forward ----------------------------------------------------------------------------------- */
 /* F1-F8, F10, F13 (+F2, F3 when fused): per-Gaussian projection, culls, EWA covariance, eigen clamp,
- * conic, tile rectangle, colour; counts the pairs of every half-tile list and plans the lists
- * (offsets, launch order).  c2w is the DEVICE [4,4] row-major camera-to-world matrix (no host read ->
+ * conic, rectangle and mask of half-tile lists, colour; counts the (list, Gaussian) pairs in total and
+ * per coarse bin.  At most 2^26 Gaussians per call.  c2w is the DEVICE [4,4] row-major camera-to-world matrix (no host read ->
  * no synchronisation).  If counts_host is not NULL the counters are copied there with hipMemcpyAsync
  * on `stream`, and counts_event (a hipEvent_t, nullable) is recorded right behind that copy: the caller
  * waits for the event (or synchronises the stream) before reading them -- it needs n_binned to size
- * the gsplat_bin buffers.  With fused inputs the SH colour pass is queued BEHIND the event, so waiting
- * on the event rather than the stream lets it run during the host's round trip.                       */
+ * the gsplat_bin buffers.  The first binning kernel and (fused inputs) the SH colour pass are queued
+ * BEHIND the event, so waiting on the event rather than the stream lets them run during the host's
+ * round trip.                                                                                          */
 int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, void* project_state,
                    void* scratch, int64_t scratch_bytes, gsplat_counts* counts_host, void* counts_event,
                    void* stream);
 
-/* F9, F11, F12: every Gaussian is appended to the lists of its rectangle and every list is sorted;
- * the order inside a list is (camera depth, Gaussian index) ascending.  The rendered image does not
+/* F9, F11, F12: every Gaussian is appended to the lists of its rectangle (two-level counting sort),
+ * the lists get their [start, end) and a longest-first launch order, and every list is sorted; the
+ * order inside a list is (camera depth, Gaussian index) ascending.  The rendered image does not
  * depend on the binning granularity, only on that order.                              */
 int gsplat_bin(int64_t n, int64_t n_binned, const gsplat_view* v, const void* project_state, void* bin_state,
                void* scratch, int64_t scratch_bytes, void* stream);
