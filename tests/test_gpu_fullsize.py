@@ -150,3 +150,24 @@ def test_large_configs_run(gs, cfg):
         g = p[k].grad
         assert g.shape == p[k].shape and torch.isfinite(g).all() and float(g.abs().max()) > 0
     print(f"config {cfg}: N={n} V={V} P={P}")
+
+
+def test_wide_image_with_more_than_16384_lists(gs):
+    """2304 x 1096 pixels = 144 x 137 = 19 728 half-tile lists: the list planning takes its multi-round path and the coarse
+    bins number 309.  Image and gradients against the C oracle (double precision)."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(77)
+    H, W, f = 1096, 2304, 900.0
+    n = 6000
+    c2w = scenes._camera(rng, tilt=0.1)
+    s = scenes._base(rng, n, H, W, f, f, W / 2.0, H / 2.0, mu_s=-3.4, sd_s=0.5, depth=(3.0, 9.0), c2w=c2w)
+    s["c2w"] = c2w
+    w = rng.uniform(0, 1, (H, W, 3)).astype(np.float32)
+    st, ref, gref, _ = c_oracle.render(s, H, W, f, f, W / 2.0, H / 2.0, grad_image=w)
+    assert st == 0
+    p = {k: torch.tensor(s[k], device=DEV).requires_grad_(True) for k in NAMES}
+    img = gs.render_gaussians(*[p[k] for k in NAMES], torch.tensor(c2w, device=DEV), H, W, f, f, W / 2.0, H / 2.0)
+    (img * torch.tensor(w, device=DEV)).sum().backward()
+    util.check_image(img.detach().cpu().numpy(), ref, frac=0.9995)
+    for k in NAMES:
+        util.check_grad(p[k].grad.cpu().numpy(), gref[k], k)
