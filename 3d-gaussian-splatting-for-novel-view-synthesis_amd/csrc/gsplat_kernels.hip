@@ -1009,6 +1009,14 @@ __global__ __launch_bounds__(64) void raster_forward_kernel(const uint2* __restr
     }
 }
 
+// x + y of a two-pixel value as ONE v_add_f32 the SLP vectoriser cannot see: left to itself it pairs these horizontal adds
+// into v_pk_add_f32 and pays three v_mov shuffles per pair (-2.5 % on the backward kernel).
+__device__ __forceinline__ float hadd(v2f a) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a.x), "v"(a.y));
+    return r;
+}
+
 // 64 per-lane partial sums v[0..63] -> their wave totals, total i delivered in lane i: a reduce-scatter.  Every level
 // halves the number of live values while it sums over one more lane bit:
 //   lane bit 5: v_permlane32_swap(v[i], v[i + 32]) + add   (2 instructions per output)
@@ -1155,7 +1163,7 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
                     const v2f ao = dal * g;
                     const v2f dq = (-0.5f * go) * (g * dal);                       // dL/dq (q un-scaled)
                     const v2f dvq = dv * dq;
-                    const float dqs = dq.x + dq.y, dvqs = dvq.x + dvq.y;
+                    const float dqs = hadd(dq), dvqs = hadd(dvq);
                     const v2f aA22 = dv * dvq;
                     // first and second moments of dL/dq over the wave's pixels; project_backward_kernel turns them into
                     // the gradients of (u, v, A11, A12, A22): d u = -2 (A11 Sx + A12 Sy), d A12 = 2 Sxy, ...
@@ -1163,9 +1171,9 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
                     r[1] = dvqs;                                                   // Sy  = sum dv dq
                     r[2] = du * r[0];                                              // Sxx = sum du^2 dq
                     r[3] = du * dvqs;                                              // Sxy = sum du dv dq
-                    r[4] = aA22.x + aA22.y;                                        // Syy = sum dv^2 dq
-                    r[5] = ao.x + ao.y;                                            // d opacity
-                    r[6] = ar.x + ar.y; r[7] = ag.x + ag.y; r[8] = ab.x + ab.y;    // d rgb
+                    r[4] = hadd(aA22);                                             // Syy = sum dv^2 dq
+                    r[5] = hadd(ao);                                               // d opacity
+                    r[6] = hadd(ar); r[7] = hadd(ag); r[8] = hadd(ab);             // d rgb
                 }
                 T = T - al * T;
             }

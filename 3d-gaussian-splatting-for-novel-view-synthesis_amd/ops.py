@@ -400,7 +400,9 @@ def render_frames(pos, f_dc, f_rest, opacity_raw, scale_raw, q_raw, c2ws, H, W, 
         nxt = begin(k + 1) if k + 1 < len(cams) else None      # queue the next frame's front before waiting for this one's counters
         image = end(k, started)
         started = nxt
+        image.record_stream(main)                              # allocated on a side stream, consumed on the caller's
         if on_frame is not None:
+            main.wait_stream(streams[k % 2])                   # GPU-side dependency only: the host does not block
             on_frame(k, image)
         else:
             images.append(image)
