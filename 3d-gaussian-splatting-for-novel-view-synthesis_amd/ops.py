@@ -380,9 +380,9 @@ def render_frames(pos, f_dc, f_rest, opacity_raw, scale_raw, q_raw, c2ws, H, W, 
     dev = pos.device
     main = torch.cuda.current_stream(dev)
     streams = _pipeline_streams(dev)
-    for st in streams:
-        st.wait_stream(main)                                   # parameters produced on the caller's stream
     cams = [torch.as_tensor(c, dtype=torch.float32, device=dev) if not isinstance(c, torch.Tensor) else c for c in c2ws]
+    for st in streams:
+        st.wait_stream(main)                                   # parameters and camera matrices produced on the caller's stream
 
     def begin(k):
         with torch.cuda.stream(streams[k % 2]):
