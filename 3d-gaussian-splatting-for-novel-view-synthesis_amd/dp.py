@@ -108,10 +108,20 @@ def data_parallel_step(render_fn, params, views, targets_grad_fn, world_views, g
     return total
 
 
-def _all_gather_cat(t, group=None):
-    """Concatenation over ranks along dim 0 of equally shaped tensors (RCCL all-gather; gloo with GPU tensors is staged
-    through the host, for rehearsals only)."""
+def _all_gather_cat(t, group=None, equal=True):
+    """Concatenation over ranks along dim 0 (RCCL all-gather; gloo with GPU tensors is staged through the host, for
+    rehearsals only).  equal=False: the ranks may hold different numbers of rows (one extra small collective for the
+    sizes, rows padded to the longest)."""
     world = dist.get_world_size(group)
+    if not equal:
+        mine = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+        sizes = _all_gather_cat(mine, group).tolist()
+        longest = max(sizes)
+        if any(sz != longest for sz in sizes):
+            pad = torch.zeros((longest,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            pad[:t.shape[0]] = t
+            full = _all_gather_cat(pad, group).view((world, longest) + tuple(t.shape[1:]))
+            return torch.cat([full[r, :sizes[r]] for r in range(world)], 0)
     if dist.get_backend(group) == "gloo" and t.is_cuda:
         parts = [torch.empty(t.shape, dtype=t.dtype) for _ in range(world)]
         dist.all_gather(parts, t.cpu(), group=group)
@@ -134,12 +144,14 @@ class FactoredExchange:
             for view in my_views: loss(render_gaussians(...)).backward()
         ex.finish()                                         # collectives + rebuild; every p.grad is final and identical on all ranks
 
-    Every rank must render the same number of views.  Works unchanged in a single process (no collective)."""
+    By default every rank must render the same number of views (equal_views=False lifts that for one extra small
+    collective per step).  Works unchanged in a single process (no collective)."""
 
     SMALL = ("pos", "opacity_raw", "scale_raw", "q_raw")
 
-    def __init__(self, params, world_views, group=None, accumulate=None, force_collectives=False):
+    def __init__(self, params, world_views, group=None, accumulate=None, force_collectives=False, equal_views=True):
         self.params, self.world_views, self.group = params, world_views, group
+        self.equal_views = equal_views
         self.logits, self.eyes = [], []
         self._accumulate = accumulate
         self._force = force_collectives          # tests: issue the collectives even in a one-rank group
@@ -179,7 +191,8 @@ class FactoredExchange:
             work = None
             if base is not None:
                 work = dist.all_reduce(base, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            logits, eyes = _all_gather_cat(logits, self.group), _all_gather_cat(eyes, self.group)
+            logits = _all_gather_cat(logits, self.group, self.equal_views)
+            eyes = _all_gather_cat(eyes, self.group, self.equal_views)
             if work is not None:
                 work.wait()
                 if self.world_views != 1:
