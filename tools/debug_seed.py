@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""For one seed of tests/test_gpu_parity.py::test_random_scenes_vs_oracle: gradient errors of the HIP path AND of the oracle
+run in float32 (= the reference's own fp32 arithmetic), both against the float64 oracle (diagnostic; needs a GPU)."""
+import importlib
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+from oracle import scenes
+from oracle import torch_port as tp
+from tests import util
+
+seed = int(sys.argv[1])
+gs = importlib.import_module("3d-gaussian-splatting-for-novel-view-synthesis_amd")
+rng = np.random.default_rng(1000 + seed)
+H, W = int(rng.integers(9, 150)), int(rng.integers(9, 200))
+n = int(rng.integers(1, 1800))
+f = float(rng.uniform(40, 160))
+cam = (H, W, f, f * float(rng.uniform(0.9, 1.1)), W / 2 + float(rng.uniform(-5, 5)), H / 2 + float(rng.uniform(-5, 5)))
+c2w = torch.tensor(scenes._camera(rng, tilt=0.3))
+s = scenes._base(rng, n, H, W, cam[2], cam[3], cam[4], cam[5], mu_s=float(rng.uniform(-3.2, -1.2)), sd_s=float(rng.uniform(0.2, 1.0)),
+                 op_mu=float(rng.uniform(-2, 3)), op_sd=1.5, spread=1.3, c2w=c2w.numpy())
+t = {k: torch.tensor(s[k]) for k in util.PARAMS}
+zc = tp.to_camera(t["pos"].double(), c2w.double())[2]
+zs, order = torch.sort(zc)
+keep = torch.ones(n, dtype=torch.bool)
+keep[order[1:][(zs[1:] - zs[:-1]) < 2e-5]] = False
+t = {k: v[keep].contiguous() for k, v in t.items()}
+w = torch.tensor(rng.uniform(0, 1, (H, W, 3)).astype(np.float32))
+print("H W n", H, W, len(t["pos"]))
+names = ("pos", "f_dc", "f_rest", "opacity_raw", "scale_raw", "q_raw")
+res = {}
+for tag, dt in (("f64", torch.float64), ("f32", torch.float32)):
+    p = {k: v.to(dt).detach().clone().requires_grad_(True) for k, v in t.items()}
+    img = tp.render_fused(*[p[k] for k in names], c2w.to(dt), *cam)
+    (img * w.to(dt)).sum().backward()
+    res[tag] = (img.detach().double().numpy(), {k: p[k].grad.double().numpy() for k in names})
+p = {k: v.to("cuda:0").detach().requires_grad_(True) for k, v in t.items()}
+img = gs.render_gaussians(*[p[k] for k in names], c2w.to("cuda:0"), *cam)
+(img * w.to("cuda:0")).sum().backward()
+res["hip"] = (img.detach().cpu().double().numpy(), {k: p[k].grad.cpu().double().numpy() for k in names})
+ref = res["f64"]
+for tag in ("f32", "hip"):
+    im, g = res[tag]
+    d = np.abs(im - ref[0])
+    print(tag, "image: mean %.2e max %.2e frac>1e-5 %.2e" % (d.mean(), d.max(), (d > 1e-5).mean()))
+    for k in names:
+        e = g[k] - ref[1][k]
+        print("   %-12s rel-L2 %.3e  max/max %.3e" % (k, np.linalg.norm(e) / (np.linalg.norm(ref[1][k]) + 1e-300), np.abs(e).max() / (np.abs(ref[1][k]).max() + 1e-300)))
