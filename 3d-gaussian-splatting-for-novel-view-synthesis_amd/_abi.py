@@ -59,6 +59,7 @@ SIGNATURES = {
     "gsplat_rasterize_forward": (_INT, [_I64, _I64, _PV, _VP, _VP, _VP, _VP, _VP, _VP]),
     "gsplat_rasterize_backward": (_INT, [_I64, _I64, _PV, _VP, _VP, _VP, _VP, _VP, C.c_int32, _VP]),
     "gsplat_project_backward": (_INT, [_PG, _VP, _PV, _VP, _VP, _PGG, _VP]),
+    "gsplat_logit_grad": (_INT, [_I64, _PV, _VP, _VP, _VP, _VP]),
     "gsplat_sh_accumulate": (_INT, [_I64, C.c_int32, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP]),
     "gsplat_build_sigma": (_INT, [_I64, _VP, _VP, _VP, _VP]),
     "gsplat_build_sigma_backward": (_INT, [_I64, _VP, _VP, _VP, _VP, _VP, _VP]),

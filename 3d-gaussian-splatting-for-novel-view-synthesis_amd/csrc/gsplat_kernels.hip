@@ -1286,7 +1286,7 @@ __global__ __launch_bounds__(64) void project_backward_kernel(gsplat_gaussians g
 #pragma unroll
             for (int k = 0; k < 3; ++k) s_dc[lane * 3 + k] *= 1.0f / GS_K0;      // each lane its own slots: no barrier needed
             __syncthreads();
-            unstage_rows<3>(out.color, s_dc, row0, g.n, lane);
+            if (out.color) unstage_rows<3>(out.color, s_dc, row0, g.n, lane);
         } else {
             unstage_rows<3>(out.f_dc, s_dc, row0, g.n, lane);
             unstage_rows<45>(out.f_rest, s_rest, row0, g.n, lane);
@@ -1295,6 +1295,22 @@ __global__ __launch_bounds__(64) void project_backward_kernel(gsplat_gaussians g
         unstage_rows<9>(out.sigma, s.a, row0, g.n, lane);
         unstage_rows<3>(out.color, s.b, row0, g.n, lane);
     }
+}
+
+// ---- colour-logit gradients straight from the raster backward's sums (data-parallel exchange) -----------
+// d L / d logit[ch] = (d L / d colour[ch]) * c (1 - c): only needs the raster backward's colour sums and the colour in the
+// record, so the all-gather of the logit gradients can start BEFORE gsplat_project_backward and overlap it.
+__global__ __launch_bounds__(256) void logit_grad_kernel(int64_t n, const uint32_t* __restrict__ tiles, const Rec64* __restrict__ rec,
+                                                         const float* __restrict__ grad2d, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float g[3] = {0.f, 0.f, 0.f};
+    if (tiles[i] != 0u) {
+        const f4 c = rec[i].r2;
+        const float* r = grad2d + i * 16;
+        g[0] = r[6] * c.x * (1.f - c.x); g[1] = r[7] * c.y * (1.f - c.y); g[2] = r[8] * c.z * (1.f - c.z);
+    }
+    out[i * 3] = g[0]; out[i * 3 + 1] = g[1]; out[i * 3 + 2] = g[2];
 }
 
 // ---- SH gradients from logit gradients (data-parallel exchange) ---------------------------------------
@@ -1573,7 +1589,7 @@ int gsplat_project_backward(const gsplat_gaussians* g, const float* c2w, const g
     if (g->n == 0) return GSPLAT_OK;
     if (!out->pos || !out->opacity_raw) return fail(GSPLAT_ERR_BAD_ARG, "grad pos / opacity_raw is NULL");
     // fused inputs, f_dc and f_rest NULL, color given: hand out the colour-logit gradients instead of the SH gradients
-    const bool factored = fused && !out->f_dc && !out->f_rest && out->color;
+    const bool factored = fused && !out->f_dc && !out->f_rest;
     if (fused && !factored && !(out->scale_raw && out->q_raw && out->f_dc && out->f_rest)) return fail(GSPLAT_ERR_BAD_ARG, "fused grads incomplete");
     if (factored && !(out->scale_raw && out->q_raw)) return fail(GSPLAT_ERR_BAD_ARG, "fused grads incomplete");
     if (!fused && !(out->color && out->sigma)) return fail(GSPLAT_ERR_BAD_ARG, "grad color / sigma is NULL");
@@ -1630,6 +1646,18 @@ int gsplat_evaluate_sh_backward(int64_t n, const float* f_dc, const float* f_res
     hipLaunchKernelGGL(evaluate_sh_backward_kernel, dim3(blocks64(n)), dim3(64), 0, (hipStream_t)stream_, n, f_dc, f_rest, points, c2w,
                        grad_color, grad_f_dc, grad_f_rest, grad_points);
     LAUNCH_CHECK("evaluate_sh_backward_kernel");
+    return GSPLAT_OK;
+}
+
+int gsplat_logit_grad(int64_t n, const gsplat_view* v, const void* project_state, const float* grad2d, float* grad_logit, void* stream_) {
+    int rc = check_view(v);
+    if (rc) return rc;
+    if (n < 0) return fail(GSPLAT_ERR_BAD_ARG, "n < 0");
+    if (n == 0) return GSPLAT_OK;
+    if (!project_state || !grad2d || !grad_logit) return fail(GSPLAT_ERR_BAD_ARG, "NULL argument");
+    ProjectState ps = carve_project((void*)project_state, n, n_lists(v));
+    hipLaunchKernelGGL(logit_grad_kernel, dim3(blocks256(n)), dim3(256), 0, (hipStream_t)stream_, n, ps.tiles, ps.rec, grad2d, grad_logit);
+    LAUNCH_CHECK("logit_grad_kernel");
     return GSPLAT_OK;
 }
 

@@ -152,13 +152,29 @@ class FactoredExchange:
     def __init__(self, params, world_views, group=None, accumulate=None, force_collectives=False, equal_views=True):
         self.params, self.world_views, self.group = params, world_views, group
         self.equal_views = equal_views
-        self.logits, self.eyes = [], []
+        self.logits, self.eyes, self._early = [], [], []
+        self._early = []                         # (gathered logits, gathered eyes, pending collectives) per local view
         self._accumulate = accumulate
         self._force = force_collectives          # tests: issue the collectives even in a one-rank group
 
+    def _distributed(self):
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self._force)
+
     def add(self, grad_logit, eye):
-        self.logits.append(grad_logit)
-        self.eyes.append(eye.detach().to(torch.float32))
+        """Called by the render backward with one view's logit gradients BEFORE it launches the projection backward: with
+        equal view counts the all-gather of this view starts here (async) and overlaps that kernel."""
+        eye = eye.detach().to(torch.float32).contiguous()
+        if self._distributed() and self.equal_views and not (dist.get_backend(self.group) == "gloo" and grad_logit.is_cuda):
+            world = dist.get_world_size(self.group)
+            n = grad_logit.shape[0]             # outputs in the concatenated form (every backend takes it), viewed per rank below
+            out = torch.empty((world * n, 3), dtype=grad_logit.dtype, device=grad_logit.device)
+            eyes = torch.empty(world * 3, dtype=torch.float32, device=eye.device)
+            works = [dist.all_gather_into_tensor(out, grad_logit.contiguous(), group=self.group, async_op=True),
+                     dist.all_gather_into_tensor(eyes, eye.reshape(3), group=self.group, async_op=True)]
+            self._early.append((out.view(world, n, 3), eyes.view(world, 3), works))
+        else:
+            self.logits.append(grad_logit)
+            self.eyes.append(eye)
 
     def __enter__(self):
         from . import ops
@@ -177,7 +193,7 @@ class FactoredExchange:
             if p[k].grad is None:
                 p[k].grad = torch.zeros_like(p[k])
             small.append(p[k].grad)
-        distributed = dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self._force)
+        distributed = self._distributed()
         n = p["pos"].shape[0]
         if self.logits:
             logits, eyes = torch.stack(self.logits), torch.stack(self.eyes)
@@ -191,8 +207,15 @@ class FactoredExchange:
             work = None
             if base is not None:
                 work = dist.all_reduce(base, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            logits = _all_gather_cat(logits, self.group, self.equal_views)
-            eyes = _all_gather_cat(eyes, self.group, self.equal_views)
+            if self._early:                      # gathered view by view since add(): just wait
+                for _, _, works in self._early:
+                    for w in works:
+                        w.wait()
+                logits = torch.cat([o for o, _, _ in self._early] + ([logits] if logits.shape[0] else []), 0)
+                eyes = torch.cat([e for _, e, _ in self._early] + ([eyes] if eyes.shape[0] else []), 0)
+            else:
+                logits = _all_gather_cat(logits, self.group, self.equal_views)
+                eyes = _all_gather_cat(eyes, self.group, self.equal_views)
             if work is not None:
                 work.wait()
                 if self.world_views != 1:
@@ -210,4 +233,4 @@ class FactoredExchange:
         for k, g in (("f_dc", g_dc), ("f_rest", g_rest)):
             g = g.to(p[k].dtype)
             p[k].grad = g if p[k].grad is None else p[k].grad + g
-        self.logits, self.eyes = [], []
+        self.logits, self.eyes, self._early = [], [], []

@@ -277,16 +277,19 @@ def _backward_impl(fr, grad_image):
         with _stage("raster_backward"):
             _abi.check(lib.gsplat_rasterize_backward(fr.n, fr.n_pairs, C.byref(fr.view), _p(fr.proj_state), _p(fr.bin_state),
                                                      _p(fr.accum), _p(gi), _p(grad2d), int(zeroed), st), "gsplat_rasterize_backward")
+        if factored:
+            # logit gradients first: the sink may start exchanging them while the projection backward runs
+            glogit = torch.empty((fr.n, 3), dtype=torch.float32, device=dev)
+            _abi.check(lib.gsplat_logit_grad(fr.n, C.byref(fr.view), _p(fr.proj_state), _p(grad2d), _p(glogit), st), "gsplat_logit_grad")
+            _sh_sink.add(glogit, fr.c2w[:3, 3])
         out = _flat_like({k: v for k, v in ins.items() if not (factored and k in ("f_dc", "f_rest"))})
-        glogit = torch.empty((fr.n, 3), dtype=torch.float32, device=dev) if factored else None
         g = _make_gaussians(fr.n, **ins)
-        gg = _abi.GaussianGrads(_p(out["pos"]), _p(out["opacity_raw"]), _p(glogit if factored else out.get("color")), _p(out.get("sigma")),
+        gg = _abi.GaussianGrads(_p(out["pos"]), _p(out["opacity_raw"]), _p(None if factored else out.get("color")), _p(out.get("sigma")),
                                 _p(out.get("scale_raw")), _p(out.get("q_raw")), _p(out.get("f_dc")), _p(out.get("f_rest")))
         with _stage("project_backward"):
             _abi.check(lib.gsplat_project_backward(C.byref(g), _p(fr.c2w), C.byref(fr.view), _p(fr.proj_state), _p(grad2d),
                                                    C.byref(gg), st), "gsplat_project_backward")
     if factored:
-        _sh_sink.add(glogit, fr.c2w[:3, 3])
         out["f_dc"] = out["f_rest"] = None
     return out
 

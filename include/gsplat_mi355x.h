@@ -151,8 +151,8 @@ int gsplat_rasterize_backward(int64_t n, int64_t n_binned, const gsplat_view* v,
                               float* grad2d, int32_t grad2d_zeroed, void* stream);
 
 /* B2 (+B3 when fused): chain the 2D gradients back to the inputs of gsplat_project.
- * Factored form (fused inputs; out->f_dc and out->f_rest NULL, out->color given): instead of the 48 SH-coefficient
- * gradients per Gaussian, out->color[n,3] receives the gradient w.r.t. the colour LOGIT (the sigmoid's argument,
+ * Factored form (fused inputs; out->f_dc and out->f_rest NULL): instead of the 48 SH-coefficient
+ * gradients per Gaussian, out->color[n,3] (if given) receives the gradient w.r.t. the colour LOGIT (the sigmoid's argument,
  * spherical_harmonics.py:166); gsplat_sh_accumulate turns logit gradients of any number of views into SH gradients.  */
 int gsplat_project_backward(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v,
                             const void* project_state, const float* grad2d, const gsplat_gaussian_grads* out,
@@ -165,6 +165,11 @@ int gsplat_project_backward(const gsplat_gaussians* g, const float* c2w, const g
  * pos[n,3]; eyes[n_views,3] = camera positions (c2w[:3,3]) on the DEVICE; grad_logit[n_views,n,3].                        */
 int gsplat_sh_accumulate(int64_t n, int32_t n_views, const float* pos, const float* eyes, const float* grad_logit,
                          float scale, float* grad_f_dc, float* grad_f_rest, void* stream);
+/* The same colour-logit gradients [n,3] straight from gsplat_rasterize_backward's grad2d (and the colours kept in
+ * project_state), without waiting for gsplat_project_backward: the exchange of the logit gradients can overlap it.
+ * (In the factored form of gsplat_project_backward out->color may then be NULL.)                                      */
+int gsplat_logit_grad(int64_t n, const gsplat_view* v, const void* project_state, const float* grad2d,
+                      float* grad_logit, void* stream);
 
 /* ---- the two small exported functions as stand-alone ops --------------------------------------- */
 int gsplat_build_sigma(int64_t n, const float* scale_raw, const float* q_raw, float* sigma, void* stream);

@@ -106,15 +106,16 @@ def _factored_inputs(rank, n=257, views=None):
     return logits, eyes, small
 
 
-def _factored_worker(rank, world, port, q):
+def _factored_worker(rank, world, port, q, even=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dp = importlib.import_module(PKG + ".dp")
     pos = torch.randn(257, 3, generator=torch.Generator().manual_seed(7))          # replicated parameters
     params = {k: torch.zeros(*s, requires_grad=True) for k, s in SHAPES.items()}
     params["pos"] = pos.clone().requires_grad_(True)
-    logits, eyes, small = _factored_inputs(rank)
-    ex = dp.FactoredExchange(params, world_views=5, accumulate=_cpu_sh_accumulate, equal_views=False)
+    logits, eyes, small = _factored_inputs(rank, views=2 if even else None)
+    # even: every rank renders 2 views -> each view's all-gather starts in add(); uneven (2 + 3): gathered in finish()
+    ex = dp.FactoredExchange(params, world_views=4 if even else 5, accumulate=_cpu_sh_accumulate, equal_views=even)
     for k, g in small.items():                   # what the render backward leaves in .grad on this rank
         params[k].grad = g.clone()
     for gl, e in zip(logits, eyes):              # ... and what it hands to the sink, one entry per view
@@ -125,13 +126,14 @@ def _factored_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_factored_exchange_world2():
+@pytest.mark.parametrize("even", [False, True])
+def test_factored_exchange_world2(even):
     """The factored exchange (all-reduce of 44 B + all-gather of the logit gradients + local rebuild) gives every rank the
     gradients the plain all-reduce of all six tensors would give."""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_factored_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_factored_worker, args=(r, world, port, q, even)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=120) for _ in range(world))
@@ -139,14 +141,15 @@ def test_factored_exchange_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     pos = torch.randn(257, 3, generator=torch.Generator().manual_seed(7))
-    ins = [_factored_inputs(r) for r in range(world)]
+    ins = [_factored_inputs(r, views=2 if even else None) for r in range(world)]
+    nv = 4 if even else 5
     all_logits = torch.stack([gl for logits, _, _ in ins for gl in logits])
     all_eyes = torch.stack([e for _, eyes, _ in ins for e in eyes])
-    e_dc, e_rest = _cpu_sh_accumulate(pos, all_eyes, all_logits, 1.0 / 5)
+    e_dc, e_rest = _cpu_sh_accumulate(pos, all_eyes, all_logits, 1.0 / nv)
     for rank in range(world):
         g = got[rank]
         for k in ("pos", "opacity_raw", "scale_raw", "q_raw"):
-            expect = sum(ins[r][2][k] for r in range(world)) / 5
+            expect = sum(ins[r][2][k] for r in range(world)) / nv
             assert torch.allclose(torch.from_numpy(g[k]), expect, atol=1e-6), k
         assert torch.allclose(torch.from_numpy(g["f_dc"]), e_dc, atol=1e-6)
         assert torch.allclose(torch.from_numpy(g["f_rest"]), e_rest, atol=1e-6)
