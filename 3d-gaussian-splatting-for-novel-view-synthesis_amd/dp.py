@@ -194,6 +194,7 @@ class FactoredExchange:
                 p[k].grad = torch.zeros_like(p[k])
             small.append(p[k].grad)
         distributed = self._distributed()
+        work = base = None
         n = p["pos"].shape[0]
         if self.logits:
             logits, eyes = torch.stack(self.logits), torch.stack(self.eyes)
@@ -204,7 +205,6 @@ class FactoredExchange:
             # the four small gradients are views of one flat buffer when they come from the render backward: one async
             # all-reduce, overlapped with the all-gather of the logit gradients
             base = _common_base(small)
-            work = None
             if base is not None:
                 work = dist.all_reduce(base, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             if self._early:                      # gathered view by view since add(): just wait
@@ -216,11 +216,7 @@ class FactoredExchange:
             else:
                 logits = _all_gather_cat(logits, self.group, self.equal_views)
                 eyes = _all_gather_cat(eyes, self.group, self.equal_views)
-            if work is not None:
-                work.wait()
-                if self.world_views != 1:
-                    base.mul_(1.0 / self.world_views)
-            else:
+            if work is None:
                 allreduce_gradients(small, self.world_views, self.group)
         elif self.world_views != 1:
             for g in small:
@@ -229,8 +225,14 @@ class FactoredExchange:
         if acc is None:
             from . import ops
             acc = ops.sh_accumulate
+        # the SH rebuild only needs the gathered logit gradients: it runs while the all-reduce of the small gradients is
+        # still in flight on the collective's stream
         g_dc, g_rest = acc(p["pos"].detach(), eyes, logits, 1.0 / self.world_views)
         for k, g in (("f_dc", g_dc), ("f_rest", g_rest)):
             g = g.to(p[k].dtype)
             p[k].grad = g if p[k].grad is None else p[k].grad + g
+        if distributed and work is not None:
+            work.wait()
+            if self.world_views != 1:
+                base.mul_(1.0 / self.world_views)
         self.logits, self.eyes, self._early = [], [], []
