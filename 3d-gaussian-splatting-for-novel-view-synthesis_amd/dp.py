@@ -171,7 +171,7 @@ class FactoredExchange:
             eyes = torch.empty(world * 3, dtype=torch.float32, device=eye.device)
             works = [dist.all_gather_into_tensor(out, grad_logit.contiguous(), group=self.group, async_op=True),
                      dist.all_gather_into_tensor(eyes, eye.reshape(3), group=self.group, async_op=True)]
-            self._early.append((out.view(world, n, 3), eyes.view(world, 3), works))
+            self._early.append((out.view(world, n, 3), eyes.view(world, 3), works + [grad_logit, eye]))   # inputs kept alive
         else:
             self.logits.append(grad_logit)
             self.eyes.append(eye)
@@ -209,7 +209,7 @@ class FactoredExchange:
                 work = dist.all_reduce(base, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             if self._early:                      # gathered view by view since add(): just wait
                 for _, _, works in self._early:
-                    for w in works:
+                    for w in works[:2]:
                         w.wait()
                 logits = torch.cat([o for o, _, _ in self._early] + ([logits] if logits.shape[0] else []), 0)
                 eyes = torch.cat([e for _, e, _ in self._early] + ([eyes] if eyes.shape[0] else []), 0)
