@@ -94,7 +94,8 @@ class Trainer:
         dev = m.pos.device
         acc = torch.zeros(3, dtype=torch.float32, device=dev)
         # data parallel: SH gradients travel in factored form (dp.FactoredExchange, 2.6x fewer bytes over xGMI at 8 views)
-        exchange = dp.FactoredExchange(m.get_params(), world_views=1, group=self.group) if world > 1 else None
+        even = global_views is None or global_views == len(views) * world       # else the ranks hold different numbers of views
+        exchange = dp.FactoredExchange(m.get_params(), world_views=1, group=self.group, equal_views=even) if world > 1 else None
         if exchange is not None:
             exchange.__enter__()
         for v in views:
