@@ -163,8 +163,8 @@ def cpu_baseline(config, sample_rows=64, sample_cols=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=3, help="synthetic scene of SURVEY.md §8d (default 3: 1M @ 1080p)")
     ap.add_argument("--forward-only", action="store_true", help="time forward-only inference instead of fwd+bwd")
     ap.add_argument("--no-cpu-baseline", action="store_true")
