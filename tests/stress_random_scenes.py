@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """One-off stress: tests/test_gpu_parity.py::test_random_scenes_vs_oracle over many more seeds (needs a GPU).
-    python tools/stress_random_scenes.py [first_seed] [count]
+    python tests/stress_random_scenes.py [first_seed] [count]
 A failure whose message is a tolerance overshoot by a few percent is usually the reference's own fp32 arithmetic
-(tools/debug_seed.py <seed> shows the oracle-in-float32 errors beside the HIP ones); anything else is a bug."""
+(tests/debug_seed.py <seed> shows the oracle-in-float32 errors beside the HIP ones); anything else is a bug."""
 import importlib
 import sys
 
