@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgsplat_mi355x.so")
+# GSPLAT_MI355X_LIB: explicit path of another build of the same library (tools/ use it for the diagnostics build)
+LIB_PATH = os.environ.get("GSPLAT_MI355X_LIB") or os.path.join(_HERE, "csrc", "libgsplat_mi355x.so")
 
 GSPLAT_OK = 0
 GSPLAT_SCENE_OK = 0

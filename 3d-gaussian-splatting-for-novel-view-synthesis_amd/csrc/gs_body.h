@@ -46,6 +46,7 @@ GS_HD ViewK make_viewk(const gsplat_view& v) {
     k.min_conis = v.min_conis; k.chi_clip = v.chi_square_clip; k.alpha_max = v.alpha_max; k.alpha_cutoff = v.alpha_cutoff;
     k.H = v.H; k.W = v.W; k.tile = v.tile;
     k.tiles_x = (v.W + v.tile - 1) / v.tile; k.tiles_y = (v.H + v.tile - 1) / v.tile;
+    k.lists_x = (v.W + LIST_W - 1) / LIST_W; k.lists_y = (v.H + LIST_H - 1) / LIST_H;
     return k;
 }
 

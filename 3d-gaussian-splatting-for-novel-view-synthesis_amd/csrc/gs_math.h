@@ -33,8 +33,13 @@ struct ViewK {
     float gl, gr, gt, gb;       // guard-band bounds: -g-cx, W+g-cx, -g-cy, H+g-cy (utils.py:82-91)
     float opacity_min;          // alpha_cutoff * 0.5 (render.py:107)
     float min_conis, chi_clip, alpha_max, alpha_cutoff;
-    int32_t H, W, tiles_x, tiles_y, tile;
+    int32_t H, W, tiles_x, tiles_y, tile;     // tile = the reference's T (render.py:62): only F10/F11's rectangle and pair count use it
+    int32_t lists_x, lists_y;                 // grid of LIST_W x LIST_H-pixel lists: what is actually binned and rasterised
 };
+
+// A "list" is the depth-ordered set of Gaussians of one 16 x 8-pixel region: the unit one wave64 rasterises.  Fixed:
+// the image does not depend on the binning granularity, so every T of the reference maps onto it.
+constexpr int LIST_W = 16, LIST_H = 8;
 
 enum : int { VIS_OK = 0, VIS_CULLED = 1, VIS_OFFSCREEN = 2 };
 
@@ -222,7 +227,7 @@ struct Proj {
     float ex, ey;                 // half-extents of {q <= chi_square_clip} along u and v (+inf if the conic is not PD)
     float opacity;
     int tx0, ty0, tx1, ty1;       // inclusive tile rectangle of the reference (F10/F11: square 2.5-sigma AABB, T x T tiles)
-    int bx0, by0, bx1, by1;       // inclusive rectangle actually binned: tight box, T x T/2 half tiles (empty: bx1 < bx0)
+    int bx0, by0, bx1, by1;       // inclusive rectangle actually binned: tight box, in 16 x 8-pixel lists (empty: bx1 < bx0)
     uint32_t bmask;               // which lists of that rectangle the ellipse can touch (binned_mask)
     int vis;                      // VIS_*
 };
@@ -251,14 +256,13 @@ GS_HD uint32_t binned_mask(const Proj& o, const ViewK& vk) {
     if (o.bx1 < o.bx0 || o.by1 < o.by0) return 0u;
     const int w = o.bx1 - o.bx0 + 1, h = o.by1 - o.by0 + 1;
     if (w * h > 32 || !(o.A11 > 0.f && o.A22 > 0.f)) return 0xFFFFFFFFu >> (w * h > 32 ? 0 : 32 - w * h);
-    const int half = vk.tile / 2;
     const float chi_pad = vk.chi_clip * 1.001f + 1e-4f, r12_22 = -o.A12 / o.A22, r12_11 = -o.A12 / o.A11;
     uint32_t m = 0u;
     int k = 0;
     for (int y = o.by0; y <= o.by1; ++y)
         for (int x = o.bx0; x <= o.bx1; ++x, ++k)
-            if (ellipse_touches_rect(o, chi_pad, r12_22, r12_11, (float)(x * vk.tile), (float)(y * half), (float)(x * vk.tile + vk.tile - 1),
-                                     (float)(y * half + half - 1)))
+            if (ellipse_touches_rect(o, chi_pad, r12_22, r12_11, (float)(x * LIST_W), (float)(y * LIST_H), (float)(x * LIST_W + LIST_W - 1),
+                                     (float)(y * LIST_H + LIST_H - 1)))
                 m |= 1u << k;
     return m;
 }
@@ -364,17 +368,16 @@ GS_HD void project_gaussian(const float p[3], const float S[6], float o_raw, con
     o.ty1 = (int)clampf_(vmax, 0.f, hm) / vk.tile;
     o.vis = VIS_OK;
     // What is binned: the tight box (the only pixels with q <= chi, i.e. alpha != 0) cut to the reference's AABB and
-    // to the image, in lists of one HALF tile (T wide, T/2 tall = one wave64 with two pixels per lane).  The image does
+    // to the image, in lists of LIST_W x LIST_H pixels (one wave64, two pixels per lane).  The image does
     // not depend on the binning: a Gaussian missing from a list has alpha = 0 on all of its pixels.
     {
         const float lo_u = fmaxf(floorf(o.u - o.ex), umin), hi_u = fminf(floorf(o.u + o.ex), umax);
         const float lo_v = fmaxf(floorf(o.v - o.ey), vmin), hi_v = fminf(floorf(o.v + o.ey), vmax);
         if (hi_u >= 0.f && lo_u <= wm && hi_v >= 0.f && lo_v <= hm && lo_u <= hi_u && lo_v <= hi_v) {
-            const int half = vk.tile / 2;
-            o.bx0 = (int)clampf_(lo_u, 0.f, wm) / vk.tile;
-            o.bx1 = (int)clampf_(hi_u, 0.f, wm) / vk.tile;
-            o.by0 = (int)clampf_(lo_v, 0.f, hm) / half;
-            o.by1 = (int)clampf_(hi_v, 0.f, hm) / half;
+            o.bx0 = (int)clampf_(lo_u, 0.f, wm) / LIST_W;
+            o.bx1 = (int)clampf_(hi_u, 0.f, wm) / LIST_W;
+            o.by0 = (int)clampf_(lo_v, 0.f, hm) / LIST_H;
+            o.by1 = (int)clampf_(hi_v, 0.f, hm) / LIST_H;
             o.bmask = binned_mask(o, vk);
         }
     }

@@ -346,8 +346,10 @@ class _RenderFn(torch.autograd.Function):
 
 def _view(H, W, fx, fy, cx, cy, near, far, pix_guard, T, min_conis, chi_square_clip, alpha_max, alpha_cutoff):
     # H, W may arrive as 0-d tensors from DataLoader collate (reference scripts/train.py:499)
-    if int(T) != 16:
-        raise NotImplementedError("the HIP rasterizer is built for T=16 tiles (the rendered image does not depend on T)")
+    # every T of the reference is accepted: the image does not depend on it; T only sets the reference's
+    # tile rectangles, i.e. the reported pair count P.  The kernels always bin 16 x 8-pixel lists.
+    if int(T) < 1:
+        raise ValueError("tile size T must be >= 1")
     return _abi.make_view(int(H), int(W), float(fx), float(fy), float(cx), float(cy), near, far, pix_guard, T, min_conis,
                           chi_square_clip, alpha_max, alpha_cutoff)
 

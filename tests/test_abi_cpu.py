@@ -64,9 +64,12 @@ def test_bad_arguments_are_rejected_without_touching_the_gpu():
     v = abi.make_view(64, 64, 50.0, 50.0, 32.0, 32.0)
     assert lib.gsplat_project(None, None, C.byref(v), None, None, 0, None, None, None) == 1
     assert b"NULL" in lib.gsplat_last_error()
+    v0 = abi.make_view(64, 64, 50.0, 50.0, 32.0, 32.0, T=0)          # every T >= 1 is accepted (reference render.py:62-64)
+    assert lib.gsplat_bin(0, 0, C.byref(v0), None, None, None, 0, None) == 1
+    assert b"T must be" in lib.gsplat_last_error()
     v8 = abi.make_view(64, 64, 50.0, 50.0, 32.0, 32.0, T=8)
     assert lib.gsplat_bin(0, 0, C.byref(v8), None, None, None, 0, None) == 1
-    assert b"T=16" in lib.gsplat_last_error()
+    assert b"state is NULL" in lib.gsplat_last_error()
 
 
 def test_no_cpu_fallback(gs):
@@ -77,8 +80,10 @@ def test_no_cpu_fallback(gs):
         gs.build_sigma_from_params(z(4, 3), z(4, 4))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         gs.evaluate_sh(z(4, 3), z(4, 45), z(4, 3), torch.eye(4))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):            # any tile size reaches the same check
         gs.render(z(4, 3), z(4, 3), z(4), z(4, 3, 3), torch.eye(4), 16, 16, 10., 10., 8., 8., T=8)
+    with pytest.raises(ValueError, match="T must be"):
+        gs.render(z(4, 3), z(4, 3), z(4), z(4, 3, 3), torch.eye(4), 16, 16, 10., 10., 8., 8., T=0)
 
 
 def test_small_helpers_match_oracle():
