@@ -944,6 +944,19 @@ __device__ __forceinline__ Staged stage_chunk(RasterLds& s, const Candidate& c, 
         qv[lane] = uint4{nn, nn, nn, nn};
         if (lane < QCAP - 64) qv[64 + lane] = uint4{nn, nn, nn, nn};
     }
+    ranks = 0ull;
+    if (MAXQ >= CHUNK) {                      // no cap (forward): queue entries written as the ballots come
+        int maxc = 0;
+#pragma unroll
+        for (int t = 0; t < N_SUB; ++t) {
+            const bool hit = (m8 >> t) & 1u;
+            const unsigned long long b = __ballot(hit);
+            if (hit) s.q[t][__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u))] = (uint16_t)(lane * 16);
+            maxc = max(maxc, (int)__popcll(b));
+        }
+        __syncthreads();
+        return Staged{n, maxc};
+    }
     unsigned long long bal[N_SUB];
     int maxc = 0;
 #pragma unroll
@@ -951,7 +964,7 @@ __device__ __forceinline__ Staged stage_chunk(RasterLds& s, const Candidate& c, 
         bal[t] = __ballot((m8 >> t) & 1u);
         maxc = max(maxc, (int)__popcll(bal[t]));
     }
-    if (MAXQ < CHUNK) {
+    {
         while (maxc > MAXQ) {                 // rare (dense lists of large Gaussians): scalar work only
             n = max(n - 4, MAXQ);             // n = MAXQ always fits
             const unsigned long long keep = (1ull << n) - 1ull;
@@ -961,7 +974,6 @@ __device__ __forceinline__ Staged stage_chunk(RasterLds& s, const Candidate& c, 
         }
         if (lane >= n) m8 = 0u;
     }
-    ranks = 0ull;
 #pragma unroll
     for (int t = 0; t < N_SUB; ++t) {
         if ((m8 >> t) & 1u) {
@@ -1207,12 +1219,20 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
         ++st_chunks;
         st_visited += (uint32_t)maxc;
         int kdone = 0;                       // iterations executed (uniform): slots [0, kdone) of every queue are valid
+        // software pipeline over the queue (LDS latency is not covered by occupancy here: 2-3 waves per SIMD): the record of
+        // iteration k + 1 and the queue entry of iteration k + 2 are requested before iteration k is evaluated
+        uint32_t o_nx = myq[0];
+        f4 a_nx = lds_at(s.r0, o_nx), b_nx = lds_at(s.r1, o_nx);
+        float cb_nx = lds_at(reinterpret_cast<const float*>(s.r2), o_nx);
+        o_nx = myq[1];
         for (int k0 = 0; k0 < maxc; k0 += 8) {
           const int k1 = min(k0 + 8, maxc);
           for (int k = k0; k < k1; ++k) {
-            const uint32_t o = myq[k];
-            const f4 a = lds_at(s.r0, o), b = lds_at(s.r1, o);
-            const float cbl = lds_at(reinterpret_cast<const float*>(s.r2), o), go = b.y;
+            const f4 a = a_nx, b = b_nx;
+            const float cbl = cb_nx, go = b.y;
+            a_nx = lds_at(s.r0, o_nx); b_nx = lds_at(s.r1, o_nx);                   // null record past the end of the queue
+            cb_nx = lds_at(reinterpret_cast<const float*>(s.r2), o_nx);
+            o_nx = myq[k + 2];                                                       // k + 2 < QCAP
             const float du = fpx - a.x;
             const v2f dv = fpy - a.y;
             const float c0 = a.z * du * du, c1 = a.w * du;
@@ -1261,6 +1281,9 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
           if (!__any(T.x > 5e-5f || T.y > 5e-5f)) break;          // every 8 entries: all pixels dead
         }
         alive_any = __any(T.x > 5e-5f || T.y > 5e-5f);        // dead pixels stay dead
+#ifdef GSPLAT_EXP_NO_GATHER
+        continue;
+#endif
         __syncthreads();
         {   // entry `lane`: add up the slots of the sub-tiles it was queued in
             float tot[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};

@@ -7,6 +7,8 @@ Functions mirror the reference's names and return values: load_image (:15), load
 load_point_cloud (:50), GaussianDataset (:153), initialize_gaussians_from_pointcloud (:287).  `write_dataset` produces
 the same layout (so a scene can be prepared without the reference's download / COLMAP tooling).  Host-side I/O only.
 """
+import json
+import pickle
 from pathlib import Path
 
 import numpy as np
@@ -19,10 +21,37 @@ def load_image(image_path):
     return torch.from_numpy(np.array(Image.open(image_path).convert('RGB'), dtype=np.float32) / 255.0)
 
 
+class _MetaUnpickler(pickle.Unpickler):
+    """Unpickler for cam_meta.npy that can only rebuild numpy arrays / scalars / dtypes and plain Python containers:
+    a crafted file cannot name any other callable, so loading a dataset directory executes nothing from it."""
+    _ALLOWED = {("numpy", "ndarray"), ("numpy", "dtype"),
+                ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+                ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+                ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer")}
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"cam_meta.npy may only hold numbers, strings, lists, dicts and numpy arrays; it names {module}.{name}")
+
+
 def load_camera_parameters(cam_meta_path):
-    """cam_meta.npy is a pickled dict in the reference's layout, so it needs allow_pickle (data_loader.py:27-47): only
-    point this at files you or the reference's tooling wrote."""
-    return np.load(cam_meta_path, allow_pickle=True).item()
+    """The camera dict of the reference's layout (data_loader.py:27-47: fx, fy[, cx, cy][, c2w] ...).  The reference stores it
+    as a PICKLED dict inside cam_meta.npy and reads it with allow_pickle=True; here the pickle is read by a restricted
+    unpickler (numpy arrays and plain containers only), and a cam_meta.json beside it (write_dataset emits one) is
+    preferred when present."""
+    path = Path(cam_meta_path)
+    js = path.with_suffix('.json')
+    if js.exists():
+        with open(js) as f:
+            return json.load(f)
+    with open(path, 'rb') as f:
+        version = np.lib.format.read_magic(f)
+        _, _, dtype = np.lib.format.read_array_header_1_0(f) if version == (1, 0) else np.lib.format.read_array_header_2_0(f)
+        if not dtype.hasobject:
+            raise ValueError(f"{path}: expected the reference's pickled dict, found a plain array")
+        obj = _MetaUnpickler(f).load()
+    return obj.item() if isinstance(obj, np.ndarray) and obj.shape == () else obj
 
 
 def _filter_points(pts):
@@ -151,7 +180,9 @@ def write_dataset(data_dir, images, fx, fy, poses, points=None, cx=None, cy=None
     meta = {'fx': float(fx), 'fy': float(fy), 'height': int(h), 'width': int(w)}
     if cx is not None and cy is not None:
         meta.update(cx=float(cx), cy=float(cy))
-    np.save(d / 'cam_meta.npy', meta, allow_pickle=True)
+    np.save(d / 'cam_meta.npy', meta, allow_pickle=True)        # the reference's format (its loader needs the pickle)
+    with open(d / 'cam_meta.json', 'w') as f:                     # same content, read in preference by load_camera_parameters
+        json.dump(meta, f)
     np.save(d / 'poses.npy', np.asarray(poses, dtype=np.float32))
     if points is not None:
         p = np.asarray(points, dtype=np.float64)

@@ -21,6 +21,31 @@ def shard_views(n_views, rank, world_size):
     return list(range(rank, n_views, world_size))
 
 
+def agree_on_views(n_local, group=None, views_per_rank=None, device=None):
+    """(equal, n_global): do all ranks render the same number of views this step, and how many views is that in all?
+
+    Every rank must reach the same answer, because it selects the sequence of collectives of the exchange (FactoredExchange
+    gathers view by view when the counts are equal and once, with a size exchange, when they are not): a rank deciding
+    from its own count alone can disagree with the others and the step hangs.  So the counts are either given by the
+    caller (`views_per_rank`: one entry per rank, the same list on every rank) or exchanged here with one tiny all-gather."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return True, int(n_local)
+    world = dist.get_world_size(group)
+    if views_per_rank is not None:
+        counts = [int(c) for c in views_per_rank]
+        if len(counts) != world:
+            raise ValueError(f"views_per_rank has {len(counts)} entries for {world} ranks")
+        if counts[dist.get_rank(group)] != int(n_local):
+            raise ValueError(f"views_per_rank says {counts[dist.get_rank(group)]} views for this rank, got {n_local}")
+    else:
+        on_gpu = dist.get_backend(group) != "gloo"
+        mine = torch.tensor([int(n_local)], dtype=torch.int64, device=device if on_gpu and device is not None else "cpu")
+        out = torch.empty(world, dtype=torch.int64, device=mine.device)
+        dist.all_gather_into_tensor(out, mine, group=group)
+        counts = out.tolist()
+    return all(c == counts[0] for c in counts), int(sum(counts))
+
+
 def _big_and_small(grads):
     """Split a list of gradient tensors into the largest (sent in place) and the rest (flattened together)."""
     order = sorted(range(len(grads)), key=lambda i: grads[i].numel(), reverse=True)
@@ -156,6 +181,13 @@ class FactoredExchange:
         self._early = []                         # (gathered logits, gathered eyes, pending collectives) per local view
         self._accumulate = accumulate
         self._force = force_collectives          # tests: issue the collectives even in a one-rank group
+
+    def owns(self, inputs):
+        """Is this render differentiating the parameters this exchange was built for (same f_dc / f_rest storage)?"""
+        try:
+            return all(inputs[k].data_ptr() == self.params[k].data_ptr() for k in ("f_dc", "f_rest"))
+        except (KeyError, AttributeError):
+            return False
 
     def _distributed(self):
         return dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self._force)

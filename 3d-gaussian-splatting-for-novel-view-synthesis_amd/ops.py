@@ -262,7 +262,9 @@ def _backward_impl(fr, grad_image):
     lib = _abi.lib()
     ins = fr.inputs
     dev = ins["pos"].device
-    factored = fr.fused and _sh_sink is not None
+    # the sink only takes over for the parameter tensors it was built for: a render of other tensors (an evaluation
+    # model, a test) while a sink is installed keeps its ordinary SH gradients
+    factored = fr.fused and _sh_sink is not None and getattr(_sh_sink, "owns", lambda _ins: True)(ins)
     if fr.empty or fr.n == 0:
         if factored:
             _sh_sink.add(torch.zeros((fr.n, 3), dtype=torch.float32, device=dev), fr.c2w[:3, 3])
@@ -315,7 +317,9 @@ class _RenderFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, fused, view, c2w, pos, opacity_raw, a, b, c, d):
-        need = any(ctx.needs_input_grad)
+        # needs_input_grad ignores the grad mode (and forward() itself always runs with grad disabled): the caller's grad mode
+        # travels in view.grad_mode.  Under torch.no_grad() nothing is saved for a backward that cannot come.
+        need = view.grad_mode and any(ctx.needs_input_grad)
         image, fr, counts = _forward_impl(fused, view, c2w, pos, opacity_raw, a, b, c, d, need)
         ctx.frame = fr
         ctx.dtypes = [t.dtype if isinstance(t, torch.Tensor) else None for t in (pos, opacity_raw, a, b, c, d)]
@@ -350,8 +354,10 @@ def _view(H, W, fx, fy, cx, cy, near, far, pix_guard, T, min_conis, chi_square_c
     # tile rectangles, i.e. the reported pair count P.  The kernels always bin 16 x 8-pixel lists.
     if int(T) < 1:
         raise ValueError("tile size T must be >= 1")
-    return _abi.make_view(int(H), int(W), float(fx), float(fy), float(cx), float(cy), near, far, pix_guard, T, min_conis,
+    view = _abi.make_view(int(H), int(W), float(fx), float(fy), float(cx), float(cy), near, far, pix_guard, T, min_conis,
                           chi_square_clip, alpha_max, alpha_cutoff)
+    view.grad_mode = torch.is_grad_enabled()            # Python-side attribute (not part of the C struct)
+    return view
 
 
 def render(pos, color, opacity_raw, sigma, c2w, H, W, fx, fy, cx, cy, near=0.01, far=100.0, pix_guard=32, T=16,

@@ -18,6 +18,7 @@ With data parallelism every rank holds the full model, renders its share of the 
 number of views; the split noise of densification comes from a generator seeded identically on all ranks, so the
 replicas stay bit-identical without a broadcast.
 """
+import contextlib
 from dataclasses import dataclass
 
 import torch
@@ -79,35 +80,37 @@ class Trainer:
         g.manual_seed(self.cfg.densify_seed * 1000003 + iteration)
         return g
 
-    def step(self, iteration, views, global_views=None):
+    def step(self, iteration, views, global_views=None, views_per_rank=None):
         """One iteration on this rank's `views` (list of dicts with image [H,W,3], c2w [4,4], H, W, fx, fy, cx, cy — the
-        sample dict of data.GaussianDataset).  `global_views` = number of views of the whole batch over all ranks
-        (default: len(views) * world size).  Returns {'loss', 'l1', 'ssim'} as device scalars (this rank's share,
-        already divided by the global batch), 'gaussians', 'lr_pos', 'densified'."""
+        sample dict of data.GaussianDataset).  Data parallel: the ranks may hold different numbers of views; how many each
+        holds is agreed COLLECTIVELY (it selects the exchange's sequence of collectives): pass `views_per_rank` (one count
+        per rank, the same list on every rank) or leave it None and the counts are exchanged with one tiny all-gather.
+        `global_views` (views of the whole batch over all ranks) is only checked against that.  Returns {'loss', 'l1',
+        'ssim'} as device scalars (this rank's share, already divided by the global batch), 'gaussians', 'lr_pos',
+        'densified'."""
         c, m = self.cfg, self.model
         world = self._world()
-        n_global = global_views if global_views is not None else len(views) * world
+        dev = m.pos.device
+        even, n_global = dp.agree_on_views(len(views), self.group, views_per_rank, device=dev)
+        if global_views is not None and int(global_views) != n_global:
+            raise ValueError(f"global_views={global_views}, but the ranks hold {n_global} views in all")
         pos_lr = optim.position_lr(iteration, c.position_lr_init, c.position_lr_final, c.position_lr_delay_mult,
                                    c.position_lr_max_steps)
         self.optimizer.param_groups[0]['lr'] = pos_lr
         self.optimizer.zero_grad()
-        dev = m.pos.device
         acc = torch.zeros(3, dtype=torch.float32, device=dev)
         # data parallel: SH gradients travel in factored form (dp.FactoredExchange, 2.6x fewer bytes over xGMI at 8 views)
-        even = global_views is None or global_views == len(views) * world       # else the ranks hold different numbers of views
         exchange = dp.FactoredExchange(m.get_params(), world_views=1, group=self.group, equal_views=even) if world > 1 else None
+        with (exchange if exchange is not None else contextlib.nullcontext()):       # the gradient sink is always removed again
+            for v in views:
+                image_gt = torch.as_tensor(v['image']).to(dev)
+                c2w = torch.as_tensor(v['c2w'], dtype=torch.float32).to(dev)
+                rendered = ops.render_gaussians(m.pos, m.f_dc, m.f_rest, m.opacity_raw, m.scale_raw, m.q_raw, c2w,
+                                                int(v['H']), int(v['W']), float(v['fx']), float(v['fy']), float(v['cx']), float(v['cy']))
+                loss, vals = losses.compute_loss_device(rendered, image_gt, c.lambda_l1, c.lambda_ssim)
+                (loss / n_global).backward()
+                acc += vals / n_global
         if exchange is not None:
-            exchange.__enter__()
-        for v in views:
-            image_gt = torch.as_tensor(v['image']).to(dev)
-            c2w = torch.as_tensor(v['c2w'], dtype=torch.float32).to(dev)
-            rendered = ops.render_gaussians(m.pos, m.f_dc, m.f_rest, m.opacity_raw, m.scale_raw, m.q_raw, c2w,
-                                            int(v['H']), int(v['W']), float(v['fx']), float(v['fy']), float(v['cx']), float(v['cy']))
-            loss, vals = losses.compute_loss_device(rendered, image_gt, c.lambda_l1, c.lambda_ssim)
-            (loss / n_global).backward()
-            acc += vals / n_global
-        if exchange is not None:
-            exchange.__exit__(None, None, None)
             exchange.finish()                 # the loss was already divided by the global batch: world_views = 1
         names = dp.PARAM_NAMES
         for k in names:

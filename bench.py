@@ -1,26 +1,38 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path on MI355X: rendered Mpix/s (forward + backward), 1M Gaussians @ 1920x1080, SH degree 3.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Either an external launcher started the ranks (`python -m torch.distributed.run ...
+bench.py --gpus N`, WORLD_SIZE set), or bench.py starts them itself: called without a launcher it re-runs itself under
+`torch.distributed.run` as a CHILD process, before this process has made any GPU call, and exits with the child's code.
+Fewer visible GPUs than N is an error (exit code 2), never a silent 1-GPU run.
 
 One step = one pass of the hot path on one camera view per rank: fused projection (covariance build + SH folded in),
 binning + sort, raster forward, raster backward, projection backward, with the upstream gradient
-dL/dimage = rand(H, W, 3; seed 1); at N > 1 followed by the RCCL all-reduce of the six parameter
-gradients (data parallel by camera view).  The scene is the synthetic config-3 scene of SURVEY.md §8d
-(seed 0), inputs resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+dL/dimage = rand(H, W, 3; seed 1); at N > 1 followed by the exchange of the parameter gradients over
+RCCL (data parallel by camera view).  The scene is the synthetic config-3 scene of SURVEY.md 8d (seed 0),
+inputs resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
   roofline      the dominant kernel's algorithmic HBM bytes per launch / its average duration (HIP events recorded on the
-                launch stream inside the timed region) against the 8 TB/s HBM peak; `traffic` from profiles/ PMC data
-                if a matching file exists, else null.
+                launch stream inside the timed region) against the 8 TB/s HBM peak; `traffic` from profiles/ PMC data.
   cpu_baseline  the CPU oracle (oracle/torch_port.py, the reference's PyTorch CPU path restated) timed on this box's
-                host cores on a bounded sample (rank 0, N = 1 only).  A reported baseline, not the target.
+                host cores on a bounded sample: a CROP of the frame (rank 0, N = 1 only).  A reported baseline, not the target.
+  sustained     >= 1 s of back-to-back steps after the timed region: ms/step mean, min and max over 10 windows.
+  N = 1 extras  (outside the timed region; --no-extras skips them) forward_only (the reference's FPS protocol,
+                scripts/render_trained.py:319-381: frame by frame, and software-pipelined render_frames), train_step
+                (render + L1/SSIM loss + backward + clip + Adam, scripts/train.py:446-569), config5 (10 M Gaussians, 4K).
+  N > 1         exchange: compute_ms (the same step without the exchange), exchange_ms (step - compute = exposed exchange
+                time), exchange_alone_ms (the collectives by themselves), bytes all-reduced / all-gathered per step, nranks.
 """
 import argparse
 import importlib
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -156,8 +168,57 @@ def cpu_baseline(config, sample_rows=64, sample_cols=None):
     t2 = time.perf_counter()
     return {"value": ch * cw / (t2 - t0) / 1e6, "unit": "Mpix/s", "cores": cores, "kind": "port",
             "sample": f"oracle/torch_port.py fwd+bwd, config {config} scene (all {len(params['pos'])} Gaussians), "
-                      f"centred {cw}x{ch} crop of the {W}x{H} image; fwd {t1 - t0:.1f}s bwd {t2 - t1:.1f}s",
+                      f"centred {cw}x{ch} CROP of the {W}x{H} image; fwd {t1 - t0:.1f}s bwd {t2 - t1:.1f}s",
             "seconds": t2 - t0}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """No launcher started us but --gpus N > 1: start the N ranks as children (torch.distributed.run).  This process has made
+    no GPU call (torch.cuda.device_count() does not initialise the device on ROCm), so nothing GPU-initialised is re-executed."""
+    rehearsal = args.single_device or args.launch_check
+    if not rehearsal:
+        visible = torch.cuda.device_count()
+        if visible < args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {visible} GPU(s) are visible: refusing to run (a 1-GPU run "
+                             f"must not be reported as {args.gpus})\n")
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(args, rank, world):
+    """Plumbing check without a GPU (tests): the ranks rendezvous, all-reduce one number and report the group's size."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(args.backend if args.backend != "nccl" or torch.cuda.is_available() else "gloo")
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "nranks": dist.get_world_size(), "sum": float(t.item()),
+                          "backend": dist.get_backend()}))
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
+def timed(fn, steps, fence):
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    fence()
+    return (time.perf_counter() - t0) / steps * 1e3
 
 
 def main():
@@ -168,19 +229,25 @@ def main():
     ap.add_argument("--config", type=int, default=3, help="synthetic scene of SURVEY.md §8d (default 3: 1M @ 1080p)")
     ap.add_argument("--forward-only", action="store_true", help="time forward-only inference instead of fwd+bwd")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip forward_only / train_step / config5 / sustained")
     ap.add_argument("--cpu-rows", type=int, default=256)
     ap.add_argument("--cpu-budget", type=int, default=150, help="seconds allowed for the CPU baseline leg")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--exchange", default="factored", choices=("factored", "allreduce"),
                     help="N > 1: SH gradients as logit gradients + local rebuild (DESIGN.md §7), or one all-reduce of all six tensors")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--launch-check", action="store_true", help="only check the rank launch + process group (no GPU needed)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.launch_check:
+        raise SystemExit(launch_check(args, rank, world))
     # CPU baseline first (rank 0, N = 1 only), before anything touches the GPU, under a time budget
     cb = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
@@ -192,6 +259,8 @@ def main():
                   "sample": f"failed: {type(e).__name__}: {e}"}
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if not args.single_device and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
     dev = torch.device("cuda", 0 if args.single_device else local_rank)
     torch.cuda.set_device(dev)
     dist = None
@@ -202,6 +271,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
     gs = importlib.import_module(PKG)
     ops = importlib.import_module(PKG + ".ops")
@@ -212,40 +283,51 @@ def main():
     H, W = cam["H"], cam["W"]
     need_grad = not args.forward_only
     params = {k: params_cpu[k].to(dev).requires_grad_(need_grad) for k in NAMES}
+    del params_cpu
     c2w = orbit_c2w(rank % 8).to(dev)                       # data parallel by camera view: rank r renders view r
     gimg = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(1)).to(dev)
     cam_args = (H, W, cam["fx"], cam["fy"], cam["cx"], cam["cy"])
 
     info = {"allreduce": None}
 
-    def step():
+    def local_step():
         if need_grad:
             for p in params.values():
                 p.grad = None
-            if world > 1 and args.exchange == "factored":
-                with dp.FactoredExchange(params, world_views=world) as ex:
-                    img = gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args)
-                    img.backward(gimg)
-                ex.finish()
-                info["allreduce"] = "factored: all-reduce of pos/opacity/scale/rotation gradients (44 B per Gaussian) + all-gather " \
-                                    "of colour-logit gradients (12 B per Gaussian and view) + local SH rebuild"
-            else:
-                img = gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args)
-                img.backward(gimg)
-            if world > 1 and args.exchange == "allreduce":
-                grads = [params[k].grad for k in NAMES]
-                info["allreduce"] = "one flat buffer, single collective" if dp._common_base(grads) is not None else "2 buckets"
-                dp.allreduce_gradients(grads, world_views=world)
+            gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args).backward(gimg)
         else:
             with torch.no_grad():
-                img = gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args)
-        return img
+                gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args)
+
+    def step():
+        if not need_grad or world == 1:
+            return local_step()
+        for p in params.values():
+            p.grad = None
+        if args.exchange == "factored":
+            with dp.FactoredExchange(params, world_views=world) as ex:
+                gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args).backward(gimg)
+            ex.finish()
+            info["allreduce"] = "factored: all-reduce of pos/opacity/scale/rotation gradients (44 B per Gaussian) + all-gather " \
+                                "of colour-logit gradients (12 B per Gaussian and view) + local SH rebuild"
+        else:
+            gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args).backward(gimg)
+            grads = [params[k].grad for k in NAMES]
+            info["allreduce"] = "one flat buffer, single collective" if dp._common_base(grads) is not None else "2 buckets"
+            dp.allreduce_gradients(grads, world_views=world)
 
     def fence():
         torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize(dev)
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     for _ in range(args.warmup):
         step()
@@ -270,15 +352,51 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     ops.set_stage_timer(None)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed)
+    ms = elapsed / args.steps * 1e3
+
+    extras = {}
+    if not args.no_extras:
+        # sustained: >= 1 s of back-to-back steps, ten windows
+        per = max(2, int(math.ceil(100.0 / ms)))
+        wins = [max_over_ranks(timed(step, per, fence)) for _ in range(10)]
+        extras["sustained"] = {"seconds": sum(wins) * per / 1e3, "steps": 10 * per, "ms_per_step": sum(wins) / 10, "min_ms": min(wins),
+                               "max_ms": max(wins), "windows": 10}
+    if world > 1 and need_grad:
+        # the same step without the exchange, and the collectives alone, on buffers of the step's sizes
+        compute_ms = max_over_ranks(timed(local_step, args.steps, fence))
+        small = torch.zeros(11 * N + 64 * 4, dtype=torch.float32, device=dev)        # pos 3 + opacity 1 + scale 3 + quat 4 floats
+        full = torch.zeros(59 * N + 64 * 6, dtype=torch.float32, device=dev) if args.exchange == "allreduce" else None
+        logit = torch.zeros(N, 3, dtype=torch.float32, device=dev)
+        gathered = torch.empty(world * N, 3, dtype=torch.float32, device=dev)
+
+        def collectives():
+            if args.exchange == "factored":
+                w1 = dist.all_gather_into_tensor(gathered, logit, async_op=True)
+                w2 = dist.all_reduce(small, async_op=True)
+                w1.wait()
+                w2.wait()
+            else:
+                dist.all_reduce(full)
+        alone_ms = None
+        if args.backend == "nccl":
+            for _ in range(2):
+                collectives()
+            alone_ms = max_over_ranks(timed(collectives, args.steps, fence))
+        extras["exchange"] = {
+            "mode": args.exchange, "nranks": dist.get_world_size(), "backend": dist.get_backend(),
+            "step_ms": ms, "compute_ms": compute_ms, "exchange_ms": ms - compute_ms, "exchange_alone_ms": alone_ms,
+            "allreduce_bytes_per_step": (44 if args.exchange == "factored" else 236) * N,
+            "allgather_bytes_per_rank_per_step": 12 * N if args.exchange == "factored" else 0,
+            "allgather_bytes_received_per_step": 12 * N * world if args.exchange == "factored" else 0,
+            "note": "exchange_ms = step - compute: the part of the exchange the step does not hide; the SH rebuild "
+                    "(gsplat_sh_accumulate) counts as exchange"}
+    if world == 1 and rank == 0 and not args.no_extras and args.config == 3 and need_grad:
+        extras.update(single_gpu_extras(gs, ops, params, cam, cam_args, dev, fence))
 
     if rank == 0:
         _, V, P = stats
         HW = H * W
-        ms = elapsed / args.steps * 1e3
         value = world * HW * args.steps / elapsed / 1e6
         stage = dict(cal_stage)
         stage.update(timer.totals_ms())              # the dominant call: measured live inside the timed region
@@ -304,12 +422,13 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(KERNEL_OF_STAGE[dom]), "kernel": KERNEL_OF_STAGE[dom],
                          "avg_launch_ms": per_stage[dom]["avg_ms"], "alg_bytes_per_launch": per_stage[dom]["alg_bytes"],
-                         "note": "the raster kernels are VALU-bound, not HBM-bound: SQ_ACTIVE_INST_VALU busy 87 % (forward) / 98 % "
-                                 "(backward) of the kernel's cycles, profiles/r01_v14_sq_counters.txt; DESIGN.md section 6"},
+                         "note": "the raster kernels are VALU-bound, not HBM-bound (DESIGN.md section 6): the HBM fraction of this "
+                                 "kernel is small by construction; pipeline_roofline prices the whole step"},
             "pipeline_roofline": {"alg_bytes_per_step": alg_total, "achieved": alg_total / (ms * 1e-3) / 1e9,
                                   "frac": alg_total / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s"},
             "stages": per_stage,
         }
+        out.update(extras)
         if cb is not None:
             out["cpu_baseline"] = cb
             if cb.get("value"):
@@ -318,6 +437,85 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def single_gpu_extras(gs, ops, params, cam, cam_args, dev, fence):
+    """N = 1, config 3, after the headline region: the other numbers BASELINE.json's configs name, each measured here so that
+    the driver's line carries them (they do not enter `value`)."""
+    out = {}
+    H, W = cam["H"], cam["W"]
+    plist = [params[k] for k in NAMES]
+    # -- forward only (config 3 of BASELINE.json; the reference's protocol: scripts/render_trained.py:319-381)
+    cams = [orbit_c2w(k % 8).to(dev) for k in range(32)]
+    with torch.no_grad():
+        def frame_by_frame():
+            for c in cams:
+                gs.render_gaussians(*plist, c, *cam_args)
+
+        def pipelined():
+            gs.render_frames(*plist, cams, *cam_args, on_frame=lambda k, im: None)
+        frame_by_frame()
+        ms_seq = timed(frame_by_frame, 2, fence) / len(cams)
+        pipelined()
+        ms_pipe = timed(pipelined, 2, fence) / len(cams)
+    out["forward_only"] = {"workload": "config 3, forward only, 32 orbit views (8 distinct poses)", "frame_by_frame_ms": ms_seq,
+                           "frame_by_frame_fps": 1e3 / ms_seq, "render_frames_ms": ms_pipe, "render_frames_fps": 1e3 / ms_pipe,
+                           "mpix_per_s": H * W / (ms_pipe * 1e-3) / 1e6}
+    # -- one training iteration (scripts/train.py:446-569): render + L1/SSIM loss + backward + clip + Adam, one view
+    model_mod = importlib.import_module(PKG + ".model")
+    training = importlib.import_module(PKG + ".training")
+    model = model_mod.GaussianModel({k: params[k].detach() for k in NAMES}, device=dev)
+    trainer = training.Trainer(model, training.TrainConfig())
+    view = {"image": torch.rand(H, W, 3, generator=torch.Generator().manual_seed(2)).to(dev), "c2w": cams[0], "H": H, "W": W,
+            "fx": cam["fx"], "fy": cam["fy"], "cx": cam["cx"], "cy": cam["cy"]}
+    it = [1]
+
+    def train_step():
+        trainer.step(it[0], [view])            # iterations 1, 2, ...: no densification (every 100), no opacity reset
+        it[0] += 1
+    for _ in range(3):
+        train_step()
+    out["train_step"] = {"workload": "config 3, Trainer.step: fused render + fused L1/SSIM loss + backward + clip + fused Adam, one view",
+                         "ms": timed(train_step, 20, fence)}
+    del trainer, model
+    # -- config 5 (10 M Gaussians, 3840 x 2160, forward + backward)
+    for p in params.values():
+        p.grad = None
+    try:
+        p5_cpu, cam5 = synthetic_scene(5)
+        p5 = {k: p5_cpu[k].to(dev).requires_grad_(True) for k in NAMES}
+        del p5_cpu
+        H5, W5 = cam5["H"], cam5["W"]
+        g5 = torch.rand(H5, W5, 3, generator=torch.Generator().manual_seed(1)).to(dev)
+        eye = torch.eye(4, device=dev)
+        a5 = (H5, W5, cam5["fx"], cam5["fy"], cam5["cx"], cam5["cy"])
+
+        def step5():
+            for p in p5.values():
+                p.grad = None
+            gs.render_gaussians(*[p5[k] for k in NAMES], eye, *a5).backward(g5)
+        for _ in range(2):
+            step5()
+        _, V5, P5 = gs.render_stats()
+        cal = ops.StageTimer()
+        ops.set_stage_timer(cal)
+        for _ in range(2):
+            step5()
+        fence()
+        ops.set_stage_timer(None)
+        st = {k: t / n for k, (n, t) in cal.totals_ms().items()}
+        ms5 = timed(step5, 5, fence)
+        N5, HW5 = p5["pos"].shape[0], H5 * W5
+        dom5 = max(st, key=st.get)
+        alg5 = (16 + 236) * N5 + (268 + 272) * V5 + 132 * P5 + 32 * HW5
+        out["config5"] = {"workload": "config 5: 10 M Gaussians, 3840x2160, SH 3, forward + backward", "ms_per_step": ms5,
+                          "mpix_per_s": HW5 / (ms5 * 1e-3) / 1e6, "V": V5, "P": P5, "stage_ms": st,
+                          "dominant": {"kernel": KERNEL_OF_STAGE[dom5], "avg_ms": st[dom5],
+                                       "frac": algorithmic_bytes(dom5, N5, V5, P5, HW5) / (st[dom5] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                          "pipeline_frac": alg5 / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    except Exception as e:                        # never take the headline line down
+        out["config5"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
 
 
 if __name__ == "__main__":

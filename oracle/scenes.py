@@ -189,9 +189,24 @@ def case_g12():  # non-default kwargs
     return s
 
 
+def _case_g14(T):  # another tile size: same scene for every T (the image must not depend on it; the pair count does)
+    rng = np.random.default_rng(114)
+    s = _base(rng, 500, 72, 104, 80.0, 84.0, 50.0, 37.0)
+    s["kwargs"] = dict(T=T)
+    return s
+
+
+def case_g14_T8():
+    return _case_g14(8)
+
+
+def case_g14_T32():
+    return _case_g14(32)
+
+
 CASES = {
     "g1_generic": case_g1, "g2_ragged": case_g2, "g3_occlusion": case_g3, "g4_thresholds": case_g4,
     "g5_guardband": case_g5, "g6_huge": case_g6, "g7_tiny": case_g7, "g8_deg0": case_g8,
     "g9a_empty_opacity": case_g9a, "g9b_empty_behind": case_g9b, "g10_offscreen": case_g10,
-    "g12_kwargs": case_g12,
+    "g12_kwargs": case_g12, "g14_T8": case_g14_T8, "g14_T32": case_g14_T32,
 }

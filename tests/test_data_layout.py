@@ -60,3 +60,21 @@ def test_written_dataset_reads_back(data, tmp_path):
     s = ds[1]
     assert np.array_equal(s['image'].numpy(), imgs[1]) and (s['fx'], s['fy'], s['cx'], s['cy'], s['H'], s['W']) == (11.0, 12.0, 7.0, 5.0, 10, 14)
     assert np.allclose(data.load_point_cloud(tmp_path / "pointcloud.ply").numpy(), pts.astype(np.float32), atol=1e-6)
+
+
+def test_cam_meta_pickle_is_read_without_executing_anything(data, tmp_path):
+    """cam_meta.npy is a pickled dict in the reference's layout: the loader rebuilds numpy arrays and plain containers only."""
+    meta = data.load_camera_parameters(os.path.join(ROOT, "cam_meta.npy"))          # written by the reference's tooling
+    assert isinstance(meta, dict) and {"fx", "fy"} <= set(meta)
+    with_pose = {"fx": 3.0, "fy": 4.0, "c2w": np.eye(4, dtype=np.float32), "n": np.float64(2.5)}
+    np.save(tmp_path / "cam_meta.npy", with_pose, allow_pickle=True)
+    got = data.load_camera_parameters(tmp_path / "cam_meta.npy")
+    assert got["fx"] == 3.0 and np.array_equal(got["c2w"], np.eye(4)) and float(got["n"]) == 2.5
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("echo pwned > " + str(tmp_path / "pwned"),))
+    np.save(tmp_path / "evil.npy", np.array(Evil(), dtype=object), allow_pickle=True)
+    with pytest.raises(Exception, match="may only hold"):
+        data.load_camera_parameters(tmp_path / "evil.npy")
+    assert not (tmp_path / "pwned").exists()

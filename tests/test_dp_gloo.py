@@ -154,3 +154,58 @@ def test_factored_exchange_world2(even):
         assert torch.allclose(torch.from_numpy(g["f_dc"]), e_dc, atol=1e-6)
         assert torch.allclose(torch.from_numpy(g["f_rest"]), e_rest, atol=1e-6)
     assert all((got[0][k] == got[1][k]).all() for k in SHAPES)          # replicas stay bit-identical
+
+
+def _uneven3_worker(rank, world, port, q, given):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dp = importlib.import_module(PKG + ".dp")
+    counts = (2, 1, 3)
+    # what Trainer.step does first: every rank must come out with the same (equal, n_global)
+    even, n_global = dp.agree_on_views(counts[rank], None, list(counts) if given else None)
+    pos = torch.randn(257, 3, generator=torch.Generator().manual_seed(7))
+    params = {k: torch.zeros(*s, requires_grad=True) for k, s in SHAPES.items()}
+    params["pos"] = pos.clone().requires_grad_(True)
+    logits, eyes, small = _factored_inputs(rank, views=counts[rank])
+    ex = dp.FactoredExchange(params, world_views=n_global, accumulate=_cpu_sh_accumulate, equal_views=even)
+    for k, g in small.items():
+        params[k].grad = g.clone()
+    for gl, e in zip(logits, eyes):
+        ex.add(gl, e)
+    ex.finish()
+    q.put((rank, even, n_global, {k: p.grad.numpy().copy() for k, p in params.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("given", [False, True])
+def test_three_ranks_with_2_1_3_views_agree_on_the_exchange(given):
+    """Rank 0 alone would see 2 * 3 == 6 views and take the equal-views path while ranks 1 and 2 take the other one (the
+    collectives then mismatch and the step hangs): the decision is made from ALL ranks' counts (exchanged, or given)."""
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_uneven3_worker, args=(r, world, port, q, given)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {r: (e, n, g) for r, e, n, g in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(e is False and n == 6 for e, n, _ in got.values())
+    pos = torch.randn(257, 3, generator=torch.Generator().manual_seed(7))
+    ins = [_factored_inputs(r, views=c) for r, c in enumerate((2, 1, 3))]
+    all_logits = torch.stack([gl for logits, _, _ in ins for gl in logits])
+    all_eyes = torch.stack([e for _, eyes, _ in ins for e in eyes])
+    e_dc, e_rest = _cpu_sh_accumulate(pos, all_eyes, all_logits, 1.0 / 6)
+    for rank in range(world):
+        g = got[rank][2]
+        for k in ("pos", "opacity_raw", "scale_raw", "q_raw"):
+            assert torch.allclose(torch.from_numpy(g[k]), sum(ins[r][2][k] for r in range(world)) / 6, atol=1e-6), k
+        assert torch.allclose(torch.from_numpy(g["f_dc"]), e_dc, atol=1e-6)
+        assert torch.allclose(torch.from_numpy(g["f_rest"]), e_rest, atol=1e-6)
+
+
+def test_agree_on_views_rejects_inconsistent_hints():
+    dp = importlib.import_module(PKG + ".dp")
+    assert dp.agree_on_views(3) == (True, 3)                       # single process: nothing to agree on

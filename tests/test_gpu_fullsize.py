@@ -29,6 +29,33 @@ def cfg3(gs):
     return s, p, cam, img, gs.render_stats()
 
 
+def _oracle_run(s, c2w, cam, w, dtype, threads=16):
+    """(image, gradients) of oracle/torch_port.py evaluated in `dtype`; float32 = the reference's own fp32 arithmetic."""
+    torch.set_num_threads(threads)
+    q = {k: torch.tensor(s[k], dtype=dtype).requires_grad_(True) for k in NAMES}
+    img = tp.render_fused(*[q[k] for k in NAMES], torch.as_tensor(c2w, dtype=dtype), *cam)
+    (img * torch.as_tensor(w, dtype=dtype)).sum().backward()
+    return img.detach().double().numpy(), {k: q[k].grad.double().numpy() for k in NAMES}
+
+
+WINDOW = (32, 524)          # rows, first row: a 1920 x 32 window of the 1080p frame (the oracle needs ~10 s per run on it)
+
+
+@pytest.fixture(scope="module")
+def cal3():
+    """Calibration for every config-3 test: all 1 M Gaussians on the window, oracle in float64 and in float32.  What the float32
+    run disagrees with the float64 run is what ANY fp32 evaluation of this scene does (flip density, gradient error)."""
+    s = scenes.synthetic_scene(3)
+    H, W, fx, fy, cx, cy = s["H"], s["W"], s["fx"], s["fy"], s["cx"], s["cy"]
+    h, y0 = WINDOW
+    w = torch.rand(h, W, 3, generator=torch.Generator().manual_seed(1))
+    win = (h, W, fx, fy, cx, cy - y0)
+    img64, g64 = _oracle_run(s, torch.eye(4), win, w, torch.float64)
+    img32, g32 = _oracle_run(s, torch.eye(4), win, w, torch.float32)
+    return dict(win=win, w=w, img64=img64, g64=g64, img32=img32, g32=g32, image=util.image_errors(img32, img64),
+                grads={k: util.grad_errors(g32[k], g64[k]) for k in NAMES})
+
+
 def test_config3_counts_match_the_reference(cfg3):
     _, _, _, img, stats = cfg3
     assert stats[1] == 973_068 and stats[2] == 2_720_508          # measured by running the reference (BASELINE.md §2)
@@ -43,7 +70,7 @@ def test_config3_forward_is_bitwise_deterministic(gs, cfg3):
     assert torch.equal(img, again)
 
 
-def test_config3_crop_consistency(gs, cfg3):
+def test_config3_crop_consistency(gs, cfg3, cal3):
     """The reference defines a per-pixel function: rendering a window (principal point shifted) must reproduce the same
     pixels, away from the window border (the guard band culls by centre, so only the outer 64 px may differ)."""
     _, p, cam, img, _ = cfg3
@@ -53,7 +80,9 @@ def test_config3_crop_consistency(gs, cfg3):
         crop = gs.render_gaussians(*[p[k] for k in NAMES], torch.eye(4, device=DEV), h, w, fx, fy, cx - x0, cy - y0)
     a = crop[64:-64, 64:-64].cpu().numpy()
     b = img[y0 + 64:y0 + h - 64, x0 + 64:x0 + w - 64].cpu().numpy()
-    util.check_image(a, b, bulk=2e-6, frac=0.9995, what="crop vs full")
+    # two fp32 evaluations with differently rounded (u, v): each flips thresholds like the float32 oracle does against float64
+    util.check_image(a, b, cal=dict(cal3["image"], bad=2 * cal3["image"]["bad"], big=2 * cal3["image"]["big"]), what="crop vs full")
+    assert np.abs(a - b).mean() < 1e-6
 
 
 def test_config3_linear_in_colour(gs, cfg3):
@@ -73,23 +102,15 @@ def test_config3_linear_in_colour(gs, cfg3):
     assert float((i3 - (0.5 * i1 + 2.0 * i2)).abs().max()) < 2e-6
 
 
-def test_config3_full_n_gradients_vs_oracle_on_a_window(gs):
-    """All 1 M Gaussians, a 1920 x 32 window of the 1080p image: image and the six gradients against the float32 oracle
-    (same ops as the reference's fp32 path) -- the oracle needs ~10 s for this."""
+def test_config3_full_n_gradients_vs_oracle_on_a_window(gs, cal3):
+    """All 1 M Gaussians, a 1920 x 32 window of the 1080p image: image and the six gradients against the float64 oracle,
+    bounds calibrated on the float32 oracle (the reference's own fp32 arithmetic) on the same window."""
     s, p, cam = _scene(3, grad=True)
-    H, W, fx, fy, cx, cy = cam
-    h, y0 = 32, 524
-    w = torch.rand(h, W, 3, generator=torch.Generator().manual_seed(1))
-    win = (h, W, fx, fy, cx, cy - y0)
-    img = gs.render_gaussians(*[p[k] for k in NAMES], torch.eye(4, device=DEV), *win)
-    (img * w.to(DEV)).sum().backward()
-    torch.set_num_threads(16)
-    q = {k: torch.tensor(s[k], dtype=torch.float64).requires_grad_(True) for k in NAMES}
-    ref = tp.render_fused(*[q[k] for k in NAMES], torch.eye(4, dtype=torch.float64), *win)
-    (ref * w.double()).sum().backward()
-    util.check_image(img.detach().cpu().numpy(), ref.detach().numpy(), frac=0.998)
+    img = gs.render_gaussians(*[p[k] for k in NAMES], torch.eye(4, device=DEV), *cal3["win"])
+    (img * cal3["w"].to(DEV)).sum().backward()
+    util.check_image(img.detach().cpu().numpy(), cal3["img64"], cal=cal3["img32"])
     for k in NAMES:
-        util.check_grad(p[k].grad.cpu().numpy(), q[k].grad.numpy(), k)
+        util.check_grad(p[k].grad.cpu().numpy(), cal3["g64"][k], k, cal=cal3["g32"][k])
 
 
 def test_config3_backward_is_reproducible_to_rounding(gs):
@@ -109,7 +130,7 @@ def test_config3_backward_is_reproducible_to_rounding(gs):
 
 
 @pytest.mark.parametrize("cfg,counts", [(2, (95_500, 304_466)), (3, (973_068, 2_720_508))])
-def test_full_frame_parity_vs_c_oracle(gs, cfg, counts):
+def test_full_frame_parity_vs_c_oracle(gs, cfg, counts, cal3):
     """BASELINE.json configs 2 and 3 at FULL size, forward + backward: image and the six gradients against the plain-C
     double-precision oracle (oracle/gs_oracle.c, itself pinned to the reference to 1e-13).  V and P are the counts the
     real reference produced on these scenes."""
@@ -117,19 +138,24 @@ def test_full_frame_parity_vs_c_oracle(gs, cfg, counts):
     s, p, cam = _scene(cfg, grad=True)
     H, W = cam[0], cam[1]
     w = np.random.default_rng(1).uniform(0, 1, (H, W, 3)).astype(np.float32)
-    # fp32 cannot order overlapping Gaussians whose depths agree to ~1e-6: compare only where the fp32 depth
-    # order is unambiguous by rendering both sides on the SAME inputs and masking nothing -- ties are rare enough here that
-    # the flip budget below absorbs them.
+    # Nothing is masked or dropped here (near depth ties included): every bound beyond SURVEY 8c's comes from the float32 oracle
+    # on the same scene -- the whole frame for config 2, the 1920 x 32 window of `cal3` for config 3 (the float32 oracle needs 45 GB
+    # and minutes for the whole 1080p frame; flip densities and relative gradient errors carry over from the window).
     img = gs.render_gaussians(*[p[k] for k in NAMES], torch.eye(4, device=DEV), *cam)
     assert gs.render_stats(img)[1:] == counts
     (img * torch.tensor(w, device=DEV)).sum().backward()
     st, ref, g, (V, P) = c_oracle.render(s, *cam, grad_image=w.astype(np.float64))
     # the float64 oracle may differ from the fp32 counts in a handful of knife-edge ceil() radii
     assert st == 0 and V == counts[0] and abs(P - counts[1]) <= 64
-    util.check_image(img.detach().cpu().numpy(), ref, frac=0.998)
+    if cfg == 2:
+        img32, g32 = _oracle_run(s, torch.eye(4), cam, w, torch.float32)
+        cal_img, cal_g = util.image_errors(img32, ref), {k: util.grad_errors(g32[k], g[k]) for k in NAMES}
+    else:
+        cal_img, cal_g = cal3["image"], cal3["grads"]
+    util.check_image(img.detach().cpu().numpy(), ref, cal=cal_img, what=f"config {cfg} image")
     assert np.abs(img.detach().cpu().numpy() - ref).mean() < 3e-6
     for k in NAMES:
-        util.check_grad(p[k].grad.cpu().numpy(), g[k], k, l2=3e-3, mx=2e-2)
+        util.check_grad(p[k].grad.cpu().numpy(), g[k], k, cal=cal_g[k])
 
 
 @pytest.mark.parametrize("cfg", [4, 5])
@@ -168,6 +194,7 @@ def test_wide_image_with_more_than_16384_lists(gs):
     p = {k: torch.tensor(s[k], device=DEV).requires_grad_(True) for k in NAMES}
     img = gs.render_gaussians(*[p[k] for k in NAMES], torch.tensor(c2w, device=DEV), H, W, f, f, W / 2.0, H / 2.0)
     (img * torch.tensor(w, device=DEV)).sum().backward()
-    util.check_image(img.detach().cpu().numpy(), ref, frac=0.9995)
+    img32, g32 = _oracle_run(s, c2w, (H, W, f, f, W / 2.0, H / 2.0), w, torch.float32)
+    util.check_image(img.detach().cpu().numpy(), ref, cal=img32)
     for k in NAMES:
-        util.check_grad(p[k].grad.cpu().numpy(), gref[k], k)
+        util.check_grad(p[k].grad.cpu().numpy(), gref[k], k, cal=g32[k])

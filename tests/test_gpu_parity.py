@@ -28,9 +28,9 @@ def test_fused_vs_reference_golden(gs, name):
     d = util.load(name)
     img, p = _fused(gs, d)
     assert img.shape == (d["H"], d["W"], 3) and img.dtype == F32 and img.device.type == "cuda"
-    util.check_image(img.detach().cpu().numpy(), d["image"])
+    util.check_image(img.detach().cpu().numpy(), d["image"], cal=d["image_f32"])
     for k in util.PARAMS:
-        util.check_grad(p[k].grad.cpu().numpy(), d["grad_" + k], k)
+        util.check_grad(p[k].grad.cpu().numpy(), d["grad_" + k], k, cal=d["grad32_" + k])
 
 
 @pytest.mark.parametrize("name", ["g1_generic", "g2_ragged", "g6_huge", "g7_tiny", "g12_kwargs"])
@@ -45,9 +45,9 @@ def test_three_call_sequence_vs_reference_golden(gs, name):
     assert np.abs(color.detach().cpu().numpy() - d["color"]).max() < 2e-6
     img = gs.render(p["pos"], color, p["opacity_raw"], sigma, c2w, *util.cam_args(d), **d["kwargs"])
     (img * torch.tensor(d["wrand"], dtype=F32, device=DEV)).sum().backward()
-    util.check_image(img.detach().cpu().numpy(), d["image"])
+    util.check_image(img.detach().cpu().numpy(), d["image"], cal=d["image_f32"])
     for k in util.PARAMS:
-        util.check_grad(p[k].grad.cpu().numpy(), d["grad_" + k], k)
+        util.check_grad(p[k].grad.cpu().numpy(), d["grad_" + k], k, cal=d["grad32_" + k])
 
 
 def test_unfused_boundary_vs_reference_golden(gs):
@@ -92,15 +92,15 @@ def test_no_grad_and_tensor_hw(gs):
         img = gs.render_gaussians(p["pos"], p["f_dc"], p["f_rest"], p["opacity_raw"], p["scale_raw"], p["q_raw"], c2w,
                                   torch.tensor(d["H"]), torch.tensor(d["W"]), d["fx"], d["fy"], d["cx"], d["cy"])
     assert not img.requires_grad
-    util.check_image(img.cpu().numpy(), d["image"])
+    util.check_image(img.cpu().numpy(), d["image"], cal=d["image_f32"])
 
 
 def test_float64_inputs_round_trip(gs):
     d = util.load("g2_ragged")
     img, p = _fused(gs, d, dtype=torch.float64)
     assert img.dtype == torch.float64 and p["pos"].grad.dtype == torch.float64
-    util.check_image(img.detach().cpu().numpy(), d["image"])
-    util.check_grad(p["f_rest"].grad.cpu().numpy(), d["grad_f_rest"], "f_rest")
+    util.check_image(img.detach().cpu().numpy(), d["image"], cal=d["image_f32"])
+    util.check_grad(p["f_rest"].grad.cpu().numpy(), d["grad_f_rest"], "f_rest", cal=d["grad32_f_rest"])
 
 
 def test_forward_is_deterministic_and_order_is_depth_then_index(gs):
@@ -164,19 +164,15 @@ def test_seeded_scene_vs_cpu_oracle(gs, n, hw, fx, mu):
     img = gs.render_gaussians(p["pos"], p["f_dc"], p["f_rest"], p["opacity_raw"], p["scale_raw"], p["q_raw"], c2w.to(DEV), *cam)
     (img * w.to(DEV)).sum().backward()
     # Threshold flips (q <= chi_square_clip, alpha >= alpha_cutoff) are inherent to fp32 and their density grows with
-    # the number of Gaussian evaluations per pixel (~20 here).  Calibrate on the oracle's own fp32-vs-fp64 disagreement
-    # (= the reference's pure-PyTorch fp32 path): the HIP path may flip at most 3x as many values, plus 1e-3.
-    with torch.no_grad():
-        ref32 = tp.render_fused(s["pos"], s["f_dc"], s["f_rest"], s["opacity_raw"], s["scale_raw"], s["q_raw"], c2w, *cam)
+    # the number of Gaussian evaluations per pixel (~20 here).  Calibrated on the oracle's own fp32-vs-fp64 disagreement
+    # (= the reference's pure-PyTorch fp32 path), image and gradients (tests/util.py).
+    img32, g32 = _oracle(s, cam, c2w, w, torch.float32)
     r64 = ref.detach().numpy()
-    bad_ref = float((np.abs(ref32.numpy() - r64) > util.IMG_TOL_BULK).mean())
     got = img.detach().cpu().numpy()
-    print(f"values beyond {util.IMG_TOL_BULK}: oracle-fp32 {bad_ref:.2e}, HIP {float((np.abs(got - r64) > util.IMG_TOL_BULK).mean()):.2e}; "
-          f"mean |delta| oracle-fp32 {np.abs(ref32.numpy() - r64).mean():.2e}, HIP {np.abs(got - r64).mean():.2e}")
-    util.check_image(got, r64, frac=1.0 - (3.0 * bad_ref + 1e-3))
+    util.check_image(got, r64, cal=img32)
     assert np.abs(got - r64).mean() < 2e-6
     for k in util.PARAMS:
-        util.check_grad(p[k].grad.cpu().numpy(), p64[k].grad.numpy(), k)
+        util.check_grad(p[k].grad.cpu().numpy(), p64[k].grad.numpy(), k, cal=g32[k])
 
 
 @pytest.mark.parametrize("n,longest", [(6000, 4096), (11000, 8192)])
@@ -207,26 +203,34 @@ def test_long_lists_take_the_large_sort_paths(gs, n, longest):
     p = {k: v.to(DEV).requires_grad_(True) for k, v in s.items()}
     img = gs.render_gaussians(p["pos"], p["f_dc"], p["f_rest"], p["opacity_raw"], p["scale_raw"], p["q_raw"], c2w.to(DEV), *cam)
     (img * w.to(DEV)).sum().backward()
-    util.check_image(img.detach().cpu().numpy(), ref.detach().numpy(), frac=0.99)
+    # thousands of layers per pixel: thousands of threshold decisions per value -> calibrated on the oracle in float32
+    img32, g32 = _oracle(s, cam, c2w, w, torch.float32)
+    util.check_image(img.detach().cpu().numpy(), ref.detach().numpy(), cal=img32)
     for k in util.PARAMS:
-        util.check_grad(p[k].grad.cpu().numpy(), p64[k].grad.numpy(), k)
+        util.check_grad(p[k].grad.cpu().numpy(), p64[k].grad.numpy(), k, cal=g32[k])
 
 
-def _vs_oracle(gs, s, cam, c2w, w, z_order_eps=None, frac=0.99):
-    p64 = {k: v.double() for k, v in s.items()}
+def _oracle(s, cam, c2w, w, dtype, z_order_eps=None):
+    """(image, gradients) of the oracle evaluated in `dtype` (float32 = the reference's own fp32 arithmetic: the calibration)."""
+    q = {k: v.to(dtype) for k, v in s.items()}
     if z_order_eps is not None:            # make (depth, index) the unique order in float64: the HIP path's tie rule
-        p64["pos"] = p64["pos"].clone()
-        p64["pos"][:, 2] += torch.arange(len(p64["pos"]), dtype=torch.float64) * z_order_eps
-    p64 = {k: v.requires_grad_(True) for k, v in p64.items()}
-    ref = tp.render_fused(p64["pos"], p64["f_dc"], p64["f_rest"], p64["opacity_raw"], p64["scale_raw"], p64["q_raw"],
-                          c2w.double(), *cam)
-    (ref * w.double()).sum().backward()
+        q["pos"] = q["pos"].clone()
+        q["pos"][:, 2] += torch.arange(len(q["pos"]), dtype=dtype) * z_order_eps
+    q = {k: v.detach().clone().requires_grad_(True) for k, v in q.items()}
+    img = tp.render_fused(q["pos"], q["f_dc"], q["f_rest"], q["opacity_raw"], q["scale_raw"], q["q_raw"], c2w.to(dtype), *cam)
+    (img * w.to(dtype)).sum().backward()
+    return img.detach().double().numpy(), {k: (v.grad.double().numpy() if v.grad is not None else np.zeros(v.shape)) for k, v in q.items()}
+
+
+def _vs_oracle(gs, s, cam, c2w, w, z_order_eps=None, calibrate=True):
+    ref, g64 = _oracle(s, cam, c2w, w, torch.float64, z_order_eps)
+    img32, g32 = _oracle(s, cam, c2w, w, torch.float32) if calibrate else (None, None)
     p = {k: v.to(DEV).requires_grad_(True) for k, v in s.items()}
     img = gs.render_gaussians(p["pos"], p["f_dc"], p["f_rest"], p["opacity_raw"], p["scale_raw"], p["q_raw"], c2w.to(DEV), *cam)
     (img * w.to(DEV)).sum().backward()
-    util.check_image(img.detach().cpu().numpy(), ref.detach().numpy(), frac=frac)
+    util.check_image(img.detach().cpu().numpy(), ref, cal=img32)
     for k in util.PARAMS:
-        util.check_grad(p[k].grad.cpu().numpy(), p64[k].grad.numpy(), k)
+        util.check_grad(p[k].grad.cpu().numpy(), g64[k], k, cal=g32[k] if calibrate else None)
     return img
 
 
@@ -244,7 +248,8 @@ def test_equal_depths_are_ordered_by_index(gs):
              opacity_raw=torch.randn(n, generator=g) * 0.3 - 3.4, f_dc=torch.randn(n, 3, generator=g),
              f_rest=torch.randn(n, 45, generator=g) * 0.2)
     w = torch.rand(H, W, 3, generator=g)
-    _vs_oracle(gs, s, (H, W, f, f, W / 2.0, H / 2.0), torch.eye(4), w, z_order_eps=1e-10)
+    # (no float32 calibration here: with every depth equal the float32 oracle's order is its argsort's whim)
+    _vs_oracle(gs, s, (H, W, f, f, W / 2.0, H / 2.0), torch.eye(4), w, z_order_eps=1e-10, calibrate=False)
     assert gs.render_stats()[2] > 0
 
 
@@ -315,7 +320,7 @@ def test_factored_sh_gradient_exchange_matches_the_plain_backward(gs):
     assert (g_rest.cpu().double() - acc[:, 1:, :].transpose(1, 2).reshape(n, 45)).abs().max() < 1e-5
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", list(range(10)) + list(range(100, 150)))
 def test_random_scenes_vs_oracle(gs, seed):
     """Randomised image sizes, cameras, anisotropies and opacities against the float64 oracle: exercises ragged list grids,
     partial coarse bins, masks of thin rotated ellipses, chunk and group boundaries of the binning and raster kernels."""
@@ -346,11 +351,13 @@ def test_random_scenes_vs_oracle(gs, seed):
     p = {k: v.to(DEV).requires_grad_(True) for k, v in t.items()}
     img = gs.render_gaussians(p["pos"], p["f_dc"], p["f_rest"], p["opacity_raw"], p["scale_raw"], p["q_raw"], c2w.to(DEV), *cam)
     (img * w.to(DEV)).sum().backward()
-    util.check_image(img.detach().cpu().numpy(), ref.detach().numpy(), frac=0.995)
+    # every bound beyond SURVEY 8c's is K_CAL x what the oracle in float32 (the reference's own fp32 arithmetic) does on this seed
+    img32, g32 = _oracle(t, cam, c2w, w, torch.float32)
+    util.check_image(img.detach().cpu().numpy(), ref.detach().numpy(), cal=img32, what=f"seed {seed} image")
     for k in util.PARAMS:
         g64 = p64[k].grad.numpy()
         if np.abs(g64).max() > 0:
-            util.check_grad(p[k].grad.cpu().numpy(), g64, k)
+            util.check_grad(p[k].grad.cpu().numpy(), g64, k, cal=g32[k])
         else:
             assert float(p[k].grad.abs().max()) == 0.0
 
@@ -377,3 +384,70 @@ def test_render_frames_is_the_frame_by_frame_result(gs):
     for a, b, (_, c) in zip(ref, got, seen):
         assert torch.equal(a, b) and torch.equal(a, c)
     assert gs.render_frames(*[p[k] for k in names], [], *util.cam_args(d)) == []
+
+
+def test_no_grad_with_parameters_saves_nothing_for_backward(gs, monkeypatch):
+    """Evaluation renders of a model's nn.Parameters under torch.no_grad() (render_trained.py:323): needs_input_grad is still
+    True there, but no accum / grad2d buffer may be allocated or written."""
+    import importlib
+    ops = importlib.import_module("3d-gaussian-splatting-for-novel-view-synthesis_amd.ops")
+    d = util.load("g1_generic")
+    p = {k: torch.nn.Parameter(v) for k, v in util.tensors(d, F32, device=DEV).items()}
+    seen = []
+    real = ops._forward_impl
+    monkeypatch.setattr(ops, "_forward_impl", lambda *a: (seen.append(a[-1]), real(*a))[1])
+    args = (p["pos"], p["f_dc"], p["f_rest"], p["opacity_raw"], p["scale_raw"], p["q_raw"], torch.tensor(d["c2w"], device=DEV), *util.cam_args(d))
+    with torch.no_grad():
+        a = gs.render_gaussians(*args)
+    b = gs.render_gaussians(*args)
+    assert seen == [False, True] and torch.equal(a, b.detach()) and b.requires_grad and not a.requires_grad
+
+
+def test_near_depth_ties_stay_in_and_tie_insensitive_results_match(gs):
+    """Nothing is dropped here: thousands of Gaussians whose camera depths differ by less than fp32 resolves (the reference's
+    argsort is not even stable there; the HIP order is (fp32 depth, index)).  What does NOT depend on how a tie is broken must
+    still match the float64 oracle: the image on every pixel that no two members of a tie cluster both cover, and all six
+    gradients of a loss that weights only those pixels."""
+    n, H, W, f = 12000, 96, 144, 120.0
+    g = torch.Generator().manual_seed(31)
+    c2w = torch.tensor(scenes.orbit_c2w(1, 24))                                    # rotated: the fp32 depth is really rounded
+    zc = 4.0 + torch.rand(n, generator=g, dtype=torch.float64) * 0.25              # mean gap 2e-5: most neighbours are near ties
+    uv = torch.stack([torch.rand(n, generator=g, dtype=torch.float64) * W, torch.rand(n, generator=g, dtype=torch.float64) * H], 1)
+    cam_pts = torch.stack([(uv[:, 0] - W / 2) / f * zc, (uv[:, 1] - H / 2) / f * zc, zc], 1)
+    pos = (cam_pts @ c2w[:3, :3].double().t() + c2w[:3, 3].double()).float()
+    s = dict(pos=pos, scale_raw=torch.randn(n, 3, generator=g) * 0.3 - 2.6, q_raw=torch.randn(n, 4, generator=g),
+             opacity_raw=torch.randn(n, generator=g) - 0.5, f_dc=torch.randn(n, 3, generator=g), f_rest=torch.randn(n, 45, generator=g) * 0.2)
+    cam = (H, W, f, f, W / 2.0, H / 2.0)
+    stages = {}
+    with torch.no_grad():
+        tp.render_fused(*[s[k].double() for k in ("pos", "f_dc", "f_rest", "opacity_raw", "scale_raw", "q_raw")], c2w.double(), *cam, stages=stages)
+    ids, u, v, con = stages["ids"], stages["u"].numpy(), stages["v"].numpy(), stages["conic"].numpy()
+    z = tp.to_camera(s["pos"].double()[ids], c2w.double())[2].numpy()              # ascending: the oracle's depth order
+    assert (np.diff(z) >= 0).all()
+    new_cluster = np.concatenate([[True], np.diff(z) >= 2e-5])
+    cluster = np.cumsum(new_cluster) - 1
+    sizes = np.bincount(cluster)
+    tied = np.nonzero(sizes[cluster] > 1)[0]
+    assert len(tied) > 0.4 * len(z)                                                # ties are the rule in this scene
+    cover = {}                                                                     # cluster -> per-pixel count of covering members
+    masked = np.zeros((H, W), bool)
+    ys, xs = np.mgrid[0:H, 0:W]
+    for i in tied:
+        du, dv = xs - u[i], ys - v[i]
+        inside = con[i, 0] * du * du + 2 * con[i, 1] * du * dv + con[i, 2] * dv * dv <= 6.25 * 1.001 + 1e-3
+        c = cover.setdefault(int(cluster[i]), np.zeros((H, W), np.int32))
+        c += inside
+    for c in cover.values():
+        masked |= c >= 2
+    print(f"{len(tied)} of {len(z)} visible Gaussians sit in near-tie clusters; {int(masked.sum())} of {H * W} pixels are covered by two of one cluster")
+    assert 0 < masked.sum() < 0.5 * H * W
+    w = torch.rand(H, W, 3, generator=g) * torch.tensor(~masked).unsqueeze(-1)
+    ref, g64 = _oracle(s, cam, c2w, w, torch.float64)
+    img32, g32 = _oracle(s, cam, c2w, w, torch.float32)
+    p = {k: t.to(DEV).requires_grad_(True) for k, t in s.items()}
+    img = gs.render_gaussians(p["pos"], p["f_dc"], p["f_rest"], p["opacity_raw"], p["scale_raw"], p["q_raw"], c2w.to(DEV), *cam)
+    (img * w.to(DEV)).sum().backward()
+    got = img.detach().cpu().numpy()
+    util.check_image(got[~masked], ref[~masked], cal=img32[~masked], what="image off the tied pixels")
+    for k in util.PARAMS:
+        util.check_grad(p[k].grad.cpu().numpy(), g64[k], k, cal=g32[k])

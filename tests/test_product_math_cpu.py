@@ -108,8 +108,9 @@ def test_forward_records_vs_reference_intermediates(hm, name):
     assert np.all(bt[has & ~small] == area[has & ~small]) and np.all(bm[has & ~small] == 0xFFFFFFFF)
     assert np.all(bt[small] == [bin(int(x)).count("1") for x in bm[small]])
     assert np.all(bm[small] >> area[small].astype(np.uint32) == 0)
-    assert np.all((br[has, 0] >= rect[has, 0]) & (br[has, 2] <= rect[has, 2]) & (br[has, 1] >= 2 * rect[has, 1]) &
-                  (br[has, 3] <= 2 * rect[has, 3] + 1))
+    T = int(d["kwargs"].get("T", 16))           # the reference's tile size: its rectangle is in T x T tiles, the lists stay 16 x 8 pixels
+    assert np.all((br[has, 0] >= rect[has, 0] * T // 16) & (br[has, 2] <= (rect[has, 2] * T + T - 1) // 16) &
+                  (br[has, 1] >= rect[has, 1] * T // 8) & (br[has, 3] <= (rect[has, 3] * T + T - 1) // 8))
     H, W = d["H"], d["W"]
     ys, xs = np.mgrid[0:H, 0:W]
     for k in range(0, len(ids), max(1, len(ids) // 200)):
@@ -117,7 +118,7 @@ def test_forward_records_vs_reference_intermediates(hm, name):
         q = con[k, 0, 0] * du * du + 2 * con[k, 0, 1] * du * dv + con[k, 1, 1] * dv * dv
         inside = q <= chi * (1 - 1e-6)
         # the reference only renders the tiles of its own rectangle
-        inside &= (xs // 16 >= rect[k, 0]) & (xs // 16 <= rect[k, 2]) & (ys // 16 >= rect[k, 1]) & (ys // 16 <= rect[k, 3])
+        inside &= (xs // T >= rect[k, 0]) & (xs // T <= rect[k, 2]) & (ys // T >= rect[k, 1]) & (ys // T <= rect[k, 3])
         if not inside.any():
             continue
         assert bt[k] > 0, k

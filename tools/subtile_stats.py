@@ -107,3 +107,37 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def exact_vs_bbox(config=3, sample=100_000, sw=4, sh=4):
+    """How many of the bounding-box sub-tiles does the ellipse {q <= chi} really touch (exact convex minimisation per rectangle)?"""
+    pos, scale, q, op, H, W, fx = scene(config)
+    u, v, ex, ey, A11, A12, A22, o = project(pos, scale, q, op, H, W, fx)
+    idx = np.random.default_rng(1).choice(len(u), size=min(sample, len(u)), replace=False)
+    u, v, ex, ey, A11, A12, A22 = (a[idx] for a in (u, v, ex, ey, A11, A12, A22))
+    x0 = np.clip(np.ceil(u - ex), 0, W - 1); x1 = np.clip(np.floor(u + ex), 0, W - 1)
+    y0 = np.clip(np.ceil(v - ey), 0, H - 1); y1 = np.clip(np.floor(v + ey), 0, H - 1)
+    ok = (np.ceil(u - ex) <= W - 1) & (np.floor(u + ex) >= 0) & (np.ceil(v - ey) <= H - 1) & (np.floor(v + ey) >= 0)
+    bb = ex_ = 0
+    for i in np.nonzero(ok)[0]:
+        for ty in range(int(y0[i]) // sh, int(y1[i]) // sh + 1):
+            for tx in range(int(x0[i]) // sw, int(x1[i]) // sw + 1):
+                bb += 1
+                rx0, rx1, ry0, ry1 = tx * sw - u[i], tx * sw + sw - 1 - u[i], ty * sh - v[i], ty * sh + sh - 1 - v[i]
+                if rx0 <= 0 <= rx1 and ry0 <= 0 <= ry1:
+                    ex_ += 1
+                    continue
+                best = 1e30
+                for X in (rx0, rx1):
+                    t = min(max(-A12[i] / A22[i] * X, ry0), ry1)
+                    best = min(best, A11[i] * X * X + (2 * A12[i] * X + A22[i] * t) * t)
+                for Y in (ry0, ry1):
+                    t = min(max(-A12[i] / A11[i] * Y, rx0), rx1)
+                    best = min(best, A22[i] * Y * Y + (2 * A12[i] * Y + A11[i] * t) * t)
+                ex_ += best <= 6.25
+    print(f"  sub-tiles {sw}x{sh}: bounding-box pairs {bb}, exact pairs {ex_}: exact / box = {ex_ / bb:.3f}")
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "exact":
+    exact_vs_bbox(int(sys.argv[1]), 30_000, 4, 4)
+    exact_vs_bbox(int(sys.argv[1]), 30_000, 4, 2)
