@@ -14,7 +14,9 @@ GSPLAT_OK = 0
 GSPLAT_SCENE_OK = 0
 GSPLAT_SCENE_ALL_CULLED = 10
 GSPLAT_SCENE_ALL_OFFSCREEN = 11
-ABI_VERSION = 2
+ABI_VERSION = 3
+GSPLAT_PROJECT_COLOUR_FUSED = 1
+GSPLAT_PROJECT_COUNTS_MAPPED = 2
 
 _F = C.POINTER(C.c_float)
 
@@ -55,10 +57,11 @@ SIGNATURES = {
     "gsplat_project_scratch_bytes": (_I64, [_I64]),
     "gsplat_bin_state_bytes": (_I64, [_I64, _PV]),
     "gsplat_bin_scratch_bytes": (_I64, [_I64, _PV]),
-    "gsplat_project": (_INT, [_PG, _VP, _PV, _VP, _VP, _I64, _VP, _VP, _VP]),
+    "gsplat_project": (_INT, [_PG, _VP, _PV, _VP, _VP, _I64, _VP, _VP, C.c_int32, _VP]),
     "gsplat_bin": (_INT, [_I64, _I64, _PV, _VP, _VP, _VP, _I64, _VP]),
     "gsplat_rasterize_forward": (_INT, [_I64, _I64, _PV, _VP, _VP, _VP, _VP, _VP, _VP]),
-    "gsplat_rasterize_backward": (_INT, [_I64, _I64, _PV, _VP, _VP, _VP, _VP, _VP, C.c_int32, _VP]),
+    "gsplat_rasterize_backward_scratch_bytes": (_I64, [_I64, _I64]),
+    "gsplat_rasterize_backward": (_INT, [_I64, _I64, _PV, _VP, _VP, _VP, _VP, _VP, C.c_int32, _VP, _I64, _VP]),
     "gsplat_project_backward": (_INT, [_PG, _VP, _PV, _VP, _VP, _PGG, _VP]),
     "gsplat_logit_grad": (_INT, [_I64, _PV, _VP, _VP, _VP, _VP]),
     "gsplat_sh_accumulate": (_INT, [_I64, C.c_int32, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP]),

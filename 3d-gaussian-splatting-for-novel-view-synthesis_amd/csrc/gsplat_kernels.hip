@@ -60,7 +60,16 @@ struct DevCounts {           // device-side counters; copied into gsplat_counts
 static_assert(sizeof(DevCounts) == sizeof(gsplat_counts), "counts layout");
 
 constexpr int COUNT_SHARDS = 256;     // per-wave counters are spread over 256 cache lines (same-address atomics serialise)
-struct alignas(64) CountShard { int32_t survivors, visible, max_tiles; uint32_t ref_pairs, bin_pairs; int32_t pad[11]; };
+struct alignas(64) CountShard { int32_t survivors, visible, max_tiles; uint32_t ref_pairs, bin_pairs, arrived; int32_t pad[10]; };
+// The caller's `scratch` of gsplat_project: counters that must be ZERO when a call starts.  The caller zeroes the block once;
+// the wave of the projection kernel that finishes last adds the shards up and clears them again (no clearing kernel, no
+// totals kernel: the front of the pipeline is latency-bound and every dependent launch costs ~5 us).
+struct CounterBlock {
+    CountShard shards[COUNT_SHARDS];
+    uint32_t done;            // shards whose waves have all added their counts (arrivals are counted per shard first: ONE word takes
+                              // only ~88 returning atomics per microsecond, 15 625 waves on it cost 0.18 ms)
+    uint32_t pad[15];
+};
 
 // A "list" is the depth-ordered set of Gaussians of one HALF tile (16 x 8 pixels): the unit one wave64 rasterises.
 // Binning is a two-level counting sort: (list, Gaussian) pairs go to coarse bins of 64 consecutive lists first
@@ -78,7 +87,6 @@ constexpr uint32_t ID_MASK = (1u << ID_BITS) - 1u;
 struct ProjectState {
     Camera* cam;
     DevCounts* counts;
-    CountShard* shards;
     Rec64* rec;
     u2* rect;                // per Gaussian: inclusive rectangle of lists
     float* depth;
@@ -105,7 +113,6 @@ ProjectState carve_project(void* base, int64_t n, int64_t nl) {
     const int64_t nb = n_bins(nl);
     s.cam = (Camera*)(p + o); o += up(sizeof(Camera));
     s.counts = (DevCounts*)(p + o); o += up(sizeof(DevCounts));
-    s.shards = (CountShard*)(p + o); o += up(sizeof(CountShard) * COUNT_SHARDS);
     s.rec = (Rec64*)(p + o); o += up(n * 64);
     s.rect = (u2*)(p + o); o += up(n * 8);
     s.depth = (float*)(p + o); o += up(n * 4);
@@ -169,27 +176,6 @@ int check_gaussians(const gsplat_gaussians* g, bool* fused) {
         if (q && (reinterpret_cast<uintptr_t>(q) & 15u)) return fail(GSPLAT_ERR_BAD_ARG, "Gaussian arrays must be 16-byte aligned");
     *fused = f;
     return GSPLAT_OK;
-}
-
-// ---- K0 ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void camera_kernel(const float* __restrict__ c2w, Camera* cam, DevCounts* counts, CountShard* shards,
-                                                     uint32_t* __restrict__ bin_total, int nb) {
-    for (int b = threadIdx.x; b < nb; b += 256) bin_total[b] = 0u;
-    if (threadIdx.x < COUNT_SHARDS) {
-        CountShard z;
-        z.survivors = 0; z.visible = 0; z.max_tiles = 0; z.ref_pairs = 0u; z.bin_pairs = 0u;
-        for (int k = 0; k < 11; ++k) z.pad[k] = 0;
-        shards[threadIdx.x] = z;
-    }
-    if (threadIdx.x == 0) {
-        float m[16];
-        for (int k = 0; k < 16; ++k) m[k] = c2w[k];
-        Camera c;
-        build_camera(m, c);
-        *cam = c;
-        counts->n_survivors = 0; counts->n_visible = 0; counts->n_pairs = 0; counts->max_tiles = 0; counts->reserved = 0;
-        counts->n_binned = 0;
-    }
 }
 
 // ---- K1 ------------------------------------------------------------------------------------------
@@ -323,15 +309,29 @@ __device__ __forceinline__ void for_each_list(u2 rect, uint32_t nt, uint32_t mas
 
 // COLOUR = false (fused inputs): geometry only, 44 of the 236 input bytes; colour_kernel evaluates the SH colour later,
 // queued behind the copy of the counters so that it runs while the host reads them and sizes the binning buffers.
+// The camera block (w2c, eye) is derived from c2w by every wave itself (16 uniform loads + 30 flops: cheaper than the launch of
+// a 1-thread kernel in front); wave 0 stores it for the later kernels.  The first waves clear the coarse-bin totals
+// bin_count_kernel accumulates into.  Epilogue: per-wave counts -> sharded counters -> the LAST wave to arrive (agent-scope
+// acq_rel counter) adds the shards up, writes the totals (device, and the caller's mapped host block if given) and leaves
+// the counter block zeroed for the next call.
 template <bool FUSED, bool COLOUR>
-__global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const Camera* __restrict__ camp, ViewK vk, Records out,
-                                                     CountShard* shards) {
+__global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const float* __restrict__ c2w, Camera* __restrict__ cam_out, ViewK vk,
+                                                     Records out, CounterBlock* cb, DevCounts* counts, DevCounts* counts_mapped,
+                                                     uint32_t* __restrict__ bin_total, int nb) {
     __shared__ ProjectLds s;
     __shared__ float s_dc[FUSED && COLOUR ? 64 * 3 : 4];
     __shared__ float s_rest[FUSED && COLOUR ? 64 * 45 : 4];
     const int lane = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * 64, i = row0 + lane;
-    const Camera cam = *camp;
+    Camera cam;
+    {
+        float m[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) m[k] = c2w[k];
+        build_camera(m, cam);
+        if (blockIdx.x == 0 && lane == 0) *cam_out = cam;
+    }
+    for (int b = blockIdx.x * 64 + lane; b < nb; b += gridDim.x * 64) bin_total[b] = 0u;
     stage_geometry<FUSED>(s, g, row0, lane);
     if (FUSED && COLOUR) {                                   // all inputs of the wave in flight at once, one wait
         stage_rows<3>(s_dc, g.f_dc, row0, g.n, lane);
@@ -371,13 +371,58 @@ __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const C
         refp += (uint32_t)__shfl_xor((int)refp, sft);
         binp += (uint32_t)__shfl_xor((int)binp, sft);
     }
+    uint32_t arrived = 0u;
     if (lane == 0) {
-        CountShard* sh = shards + (blockIdx.x % COUNT_SHARDS);
+        CountShard* sh = cb->shards + (blockIdx.x % COUNT_SHARDS);
         if (surv) atomicAdd(&sh->survivors, (int)__popcll(surv));
         if (seen) atomicAdd(&sh->visible, (int)__popcll(seen));
         if (mx) atomicMax(&sh->max_tiles, (int)mx);
         if (refp) atomicAdd(&sh->ref_pairs, refp);
         if (binp) atomicAdd(&sh->bin_pairs, binp);
+        // The adds above are agent-scope atomics (performed at the memory side, coherent without any cache maintenance); they
+        // only have to be COMPLETE before this wave reports in: s_waitcnt vmcnt(0) (atomics stay counted until performed).  (An
+        // agent-scope release fence here costs an L2 write-back per wave: 15 625 of them took 0.8 ms.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // arrival, two levels: last wave of its shard -> last shard of the grid
+        const uint32_t shard = blockIdx.x % COUNT_SHARDS, shards_used = min(gridDim.x, (uint32_t)COUNT_SHARDS);
+        const uint32_t waves_of_shard = (gridDim.x - shard + COUNT_SHARDS - 1u) / COUNT_SHARDS;
+        arrived = 0u;
+        if (__hip_atomic_fetch_add(&sh->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == waves_of_shard - 1u)
+            arrived = (__hip_atomic_fetch_add(&cb->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards_used - 1u) ? 1u : 0u;
+    }
+    arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
+    if (!arrived) return;
+    // ---- last wave: totals of the 256 shards (4 per lane; agent-scope atomic loads: the adds were made at that scope)
+    unsigned long long t4[4] = {0ull, 0ull, 0ull, 0ull};
+    uint32_t mxt = 0u;
+#pragma unroll
+    for (int k = 0; k < COUNT_SHARDS / 64; ++k) {
+        CountShard* sh = cb->shards + k * 64 + lane;
+        t4[0] += (unsigned long long)(uint32_t)__hip_atomic_load(&sh->survivors, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t4[1] += (unsigned long long)(uint32_t)__hip_atomic_load(&sh->visible, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t4[2] += (unsigned long long)__hip_atomic_load(&sh->ref_pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t4[3] += (unsigned long long)__hip_atomic_load(&sh->bin_pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mxt = max(mxt, (uint32_t)__hip_atomic_load(&sh->max_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        // leave the block zeroed for the next call (agent-scope stores: not parked in this XCD's L2 behind the atomics)
+        __hip_atomic_store(&sh->survivors, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sh->visible, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sh->ref_pairs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sh->bin_pairs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sh->max_tiles, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sh->arrived, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int sft = 32; sft > 0; sft >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t4[k] += (unsigned long long)__shfl_xor((long long)t4[k], sft);
+        mxt = max(mxt, (uint32_t)__shfl_xor((int)mxt, sft));
+    }
+    if (lane == 0) {
+        DevCounts c;
+        c.n_survivors = (int32_t)t4[0]; c.n_visible = (int32_t)t4[1]; c.n_pairs = (int64_t)t4[2]; c.max_tiles = (int32_t)mxt;
+        c.reserved = 0; c.n_binned = (int64_t)t4[3];
+        *counts = c;
+        if (counts_mapped) *counts_mapped = c;               // pinned host memory: visible to the host once the event behind us fires
+        __hip_atomic_store(&cb->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -404,36 +449,6 @@ __global__ __launch_bounds__(64) void colour_kernel(gsplat_gaussians g, const Ca
         sh_colour(sm, ShCoefLds{s_dc + lane * 3, s_rest + lane * 45}, rgb);
         float* r2 = reinterpret_cast<float*>(&rec[i].r2);
         r2[0] = rgb[0]; r2[1] = rgb[1]; r2[2] = rgb[2];
-    }
-}
-
-// ---- K2: counter totals ----------------------------------------------------------------------------
-__global__ __launch_bounds__(COUNT_SHARDS) void finish_counts_kernel(const CountShard* __restrict__ shards, DevCounts* counts) {
-    __shared__ unsigned long long part[5][COUNT_SHARDS / 64];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const CountShard sh = shards[tid];
-    unsigned long long v[4] = {(unsigned long long)sh.survivors, (unsigned long long)sh.visible, (unsigned long long)sh.ref_pairs,
-                               (unsigned long long)sh.bin_pairs};
-    uint32_t mxt = (uint32_t)sh.max_tiles;
-    for (int sft = 32; sft > 0; sft >>= 1) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] += (unsigned long long)__shfl_xor((long long)v[k], sft);
-        mxt = max(mxt, (uint32_t)__shfl_xor((int)mxt, sft));
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) part[k][tid >> 6] = v[k];
-        part[4][tid >> 6] = mxt;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        unsigned long long t[5] = {0, 0, 0, 0, 0};
-        for (int w = 0; w < COUNT_SHARDS / 64; ++w) {
-            for (int k = 0; k < 4; ++k) t[k] += part[k][w];
-            t[4] = max(t[4], part[4][w]);
-        }
-        counts->n_survivors = (int32_t)t[0]; counts->n_visible = (int32_t)t[1]; counts->n_pairs = (int64_t)t[2];
-        counts->n_binned = (int64_t)t[3]; counts->max_tiles = (int32_t)t[4];
     }
 }
 
@@ -552,13 +567,24 @@ __device__ __forceinline__ int bin_of_pair(const uint32_t* __restrict__ bin_star
 
 __device__ __forceinline__ uint32_t local_list(uint64_t v) { return (uint32_t)(v >> ID_BITS) & ((1u << BIN_SHIFT) - 1u); }
 
+// The grids of the two kernels come from the CAPACITY of the pair buffers (the host need not know the count); the pairs
+// really binned are counts->n_binned.  More pairs than the buffers hold: only the first `capacity` are processed and the
+// ranges are clipped to the buffers -- memory-safe garbage; the caller sees n_binned > capacity in the counters and renders
+// the frame again with larger buffers.
+__device__ __forceinline__ uint32_t pairs_to_process(const DevCounts* counts, uint32_t capacity) {
+    const long long nb_ = counts->n_binned;
+    return nb_ < (long long)capacity ? (uint32_t)nb_ : capacity;
+}
+
 __global__ __launch_bounds__(256) void split_count_kernel(int nb, const uint32_t* __restrict__ bin_start, const uint64_t* __restrict__ bvals,
-                                                          uint32_t n_binned, uint32_t* __restrict__ list_count,
-                                                          uint32_t* __restrict__ seg_off) {
+                                                          uint32_t capacity, const DevCounts* __restrict__ counts,
+                                                          uint32_t* __restrict__ list_count, uint32_t* __restrict__ seg_off) {
     constexpr int L = 1 << BIN_SHIFT, U = SPLIT_CHUNK / 256;
     __shared__ uint32_t cnt[L];
     const int tid = threadIdx.x;
+    const uint32_t n_binned = pairs_to_process(counts, capacity);
     const uint32_t c0 = blockIdx.x * (uint32_t)SPLIT_CHUNK, c1 = min(c0 + (uint32_t)SPLIT_CHUNK, n_binned);
+    if (c0 >= n_binned) return;
     for (int b = bin_of_pair(bin_start, nb, c0); b < nb && bin_start[b] < c1; ++b) {
         const uint32_t s = max(c0, bin_start[b]), e = min(c1, bin_start[b + 1]);
         if (s >= e) continue;                                  // empty bin (uniform)
@@ -580,13 +606,16 @@ __global__ __launch_bounds__(256) void split_count_kernel(int nb, const uint32_t
 }
 
 __global__ __launch_bounds__(256) void split_scatter_kernel(int nl, int nb, const uint32_t* __restrict__ bin_start,
-                                                            const uint64_t* __restrict__ bvals, uint32_t n_binned,
+                                                            const uint64_t* __restrict__ bvals, uint32_t capacity,
+                                                            const DevCounts* __restrict__ counts,
                                                             const uint32_t* __restrict__ list_count, const uint32_t* __restrict__ seg_off,
                                                             uint2* __restrict__ ranges, uint64_t* __restrict__ vals) {
     constexpr int L = 1 << BIN_SHIFT, U = SPLIT_CHUNK / 256;
     __shared__ uint32_t cur[L];
     const int tid = threadIdx.x;
+    const uint32_t n_binned = pairs_to_process(counts, capacity);
     const uint32_t c0 = blockIdx.x * (uint32_t)SPLIT_CHUNK, c1 = min(c0 + (uint32_t)SPLIT_CHUNK, n_binned);
+    if (c0 >= n_binned) return;
     for (int b = bin_of_pair(bin_start, nb, c0); b < nb && bin_start[b] < c1; ++b) {
         const uint32_t bs = bin_start[b], s = max(c0, bs), e = min(c1, bin_start[b + 1]);
         if (s >= e) continue;
@@ -600,7 +629,7 @@ __global__ __launch_bounds__(256) void split_scatter_kernel(int nl, int nb, cons
             const uint32_t st = bs + incl - c;
             cur[tid] = st + seg_off[((int64_t)blockIdx.x + b) * L + tid];      // garbage where the segment has no pair: unused
             const int list = b * L + tid;
-            if (s == bs && list < nl) ranges[list] = uint2{st, st + c};
+            if (s == bs && list < nl) ranges[list] = uint2{min(st, capacity), min(st + c, capacity)};    // (clipped: overflow only)
         }
         __syncthreads();
         uint64_t v[U];
@@ -1151,12 +1180,24 @@ struct RasterLdsBwd {
 // Every group reduces its Gaussian's nine sums over its 8 lanes (reduce-scatter: 8 Gaussians at once in the same
 // instructions); the rows of a chunk leave with ONE 36-byte global atomic request per (list, Gaussian) pair, 7 rows per
 // instruction (the memory-side atomic units take ~20 G requests/s: per sub-tile requests would cost 3x the time).
+//
+// DET (deterministic gradients): float atomics add in arrival order, so gradients differ from run to run at the 1e-6 level.
+// With DET the rows are STORED instead, one row per (list, Gaussian) pair at slot pair_base[Gaussian] + (ordinal of the list
+// in the Gaussian's own rectangle), and pair_reduce_kernel adds each Gaussian's rows in that fixed order: bitwise
+// reproducible (the sums inside a wave are already in a fixed order).
+struct DetArgs {
+    const u2* rect; const uint32_t* mask; const uint32_t* tiles; const uint32_t* pair_base;
+    float* part;             // [pair capacity][9]
+    uint32_t capacity;
+};
+
+template <bool DET>
 __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ ids,
                                                              const Rec64* __restrict__ rec, const uint32_t* __restrict__ order,
                                                              int lists_x, int H, int W, float chi, float alpha_max,
                                                              float alpha_cutoff, const float* __restrict__ accum,
                                                              const float* __restrict__ gimg, float* __restrict__ grad2d,
-                                                             WaveStats* __restrict__ stats, uint32_t id_max) {
+                                                             WaveStats* __restrict__ stats, uint32_t id_max, DetArgs det) {
     __shared__ RasterLdsBwd sb;
     RasterLds& s = sb.f;
     const int lane = threadIdx.x;
@@ -1299,18 +1340,99 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
 #pragma unroll
             for (int v = 0; v < 9; ++v) sb.acc[lane * 9 + v] = tot[v];
         }
+        if (DET && lane < n) {       // entry `lane`: its row's slot = first slot of its Gaussian + ordinal of this list in its rectangle
+            const uint32_t id = __float_as_uint(s.r2[lane].y);
+            const u2 rc = det.rect[id];
+            const uint32_t mk = det.mask[id], nt = det.tiles[id];
+            const int x0 = (int)(rc.x & 0xFFFFu), y0 = (int)(rc.x >> 16), x1 = (int)(rc.y & 0xFFFFu);
+            const uint32_t bit = (uint32_t)((hy - y0) * (x1 - x0 + 1) + (tx - x0));          // row-major, like for_each_list
+            const uint32_t ord = nt > 32u ? bit : (uint32_t)__popc(mk & ((1u << (bit & 31u)) - 1u));
+            s.r2[lane].z = __uint_as_float(det.pair_base[id] + ord);
+        }
         __syncthreads();
         // the chunk's rows -> grad2d: 7 rows x 9 sums per atomic instruction, one 36-byte request per row
         for (int t0 = 0; t0 < n; t0 += 7) {
             const int c = t0 + my_g;
             if (lane < 63 && c < n) {
                 const float val = sb.acc[c * 9 + my_k];
-                if (val != 0.0f) atomicAdd(&grad2d[(int64_t)__float_as_uint(s.r2[c].y) * 16 + my_k], val);
+                if (DET) {
+                    const uint32_t slot = __float_as_uint(s.r2[c].z);
+                    if (slot < det.capacity) det.part[(int64_t)slot * 9 + my_k] = val;
+                } else if (val != 0.0f) {
+                    atomicAdd(&grad2d[(int64_t)__float_as_uint(s.r2[c].y) * 16 + my_k], val);
+                }
             }
         }
     }
     if (stats && lane == 0)
         stats[list] = WaveStats{rg.y - rg.x, st_chunks, st_visited, (uint32_t)(__builtin_amdgcn_s_memtime() - t_begin)};
+}
+
+// ---- deterministic mode: slots of the (list, Gaussian) rows and their fixed-order sum ------------------------------------
+constexpr int PB_BLOCK = 2048;                       // Gaussians per block of the two kernels below
+__global__ __launch_bounds__(256) void tile_block_sum_kernel(int64_t n, const uint32_t* __restrict__ tiles, uint32_t* __restrict__ block_sum) {
+    __shared__ uint32_t ws[4];
+    uint32_t t = 0u;
+    for (int k = 0; k < PB_BLOCK / 256; ++k) {
+        const int64_t i = (int64_t)blockIdx.x * PB_BLOCK + k * 256 + threadIdx.x;
+        t += i < n ? tiles[i] : 0u;
+    }
+    for (int sft = 32; sft > 0; sft >>= 1) t += (uint32_t)__shfl_xor((int)t, sft);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// pair_base[i] = number of rows of the Gaussians before i (exclusive scan of tiles[]): thread t of a block owns 8 CONSECUTIVE
+// Gaussians, so the scan order is the index order.
+__global__ __launch_bounds__(256) void pair_base_kernel(int64_t n, const uint32_t* __restrict__ tiles, const uint32_t* __restrict__ block_sum,
+                                                        uint32_t* __restrict__ pair_base) {
+    __shared__ uint32_t ws[4], s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t before = 0u;
+    for (int b = tid; b < (int)blockIdx.x; b += 256) before += block_sum[b];
+    for (int sft = 32; sft > 0; sft >>= 1) before += (uint32_t)__shfl_xor((int)before, sft);
+    if (lane == 0) ws[wave] = before;
+    __syncthreads();
+    if (tid == 0) s_base = ws[0] + ws[1] + ws[2] + ws[3];
+    __syncthreads();
+    constexpr int K = PB_BLOCK / 256;
+    uint32_t v[K], run = 0u;
+    const int64_t i0 = (int64_t)blockIdx.x * PB_BLOCK + (int64_t)tid * K;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { v[k] = i0 + k < n ? tiles[i0 + k] : 0u; run += v[k]; }
+    uint32_t incl = run;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up_ = (uint32_t)__shfl_up((int)incl, d);
+        if (lane >= d) incl += up_;
+    }
+    __syncthreads();
+    if (lane == 63) ws[wave] = incl;
+    __syncthreads();
+    uint32_t st = s_base + incl - run;
+    for (int k = 0; k < wave; ++k) st += ws[k];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (i0 + k < n) pair_base[i0 + k] = st;
+        st += v[k];
+    }
+}
+
+// grad2d[i][0..8] = sum of Gaussian i's rows, in the order of its lists (row-major in its rectangle): the same order every run.
+__global__ __launch_bounds__(256) void pair_reduce_kernel(int64_t n, const uint32_t* __restrict__ tiles, const uint32_t* __restrict__ pair_base,
+                                                          const float* __restrict__ part, uint32_t capacity, float* __restrict__ grad2d) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float t[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const uint32_t nt = tiles[i], pb = pair_base[i];
+    for (uint32_t k = 0; k < nt && pb + k < capacity; ++k) {
+        const float* row = part + (int64_t)(pb + k) * 9;
+#pragma unroll
+        for (int v = 0; v < 9; ++v) t[v] += row[v];
+    }
+    float* o = grad2d + i * 16;
+#pragma unroll
+    for (int v = 0; v < 9; ++v) o[v] = t[v];
 }
 
 // ---- K8 ------------------------------------------------------------------------------------------
@@ -1559,50 +1681,58 @@ int64_t gsplat_project_state_bytes(int64_t n, const gsplat_view* v) {
     return carve_project(nullptr, n > 0 ? n : 1, n_lists(v)).bytes;
 }
 
-int64_t gsplat_project_scratch_bytes(int64_t n) { (void)n; return ALIGN; }        // nothing needed since ABI 2
+int64_t gsplat_project_scratch_bytes(int64_t n) { (void)n; return up(sizeof(CounterBlock)); }   // the persistent counter block
 
-int64_t gsplat_bin_state_bytes(int64_t n_binned, const gsplat_view* v) {
+int64_t gsplat_bin_state_bytes(int64_t pair_capacity, const gsplat_view* v) {
     if (!v) return -1;
-    return up((n_binned > 0 ? n_binned : 1) * 4);                                   // sorted ids
+    return up((pair_capacity > 0 ? pair_capacity : 1) * 4);                         // sorted ids
 }
 
-int64_t gsplat_bin_scratch_bytes(int64_t n_binned, const gsplat_view* v) {
+int64_t gsplat_bin_scratch_bytes(int64_t pair_capacity, const gsplat_view* v) {
     if (!v) return -1;
-    return carve_bin_scratch(nullptr, n_binned, n_bins(n_lists(v))).bytes;
+    return carve_bin_scratch(nullptr, pair_capacity, n_bins(n_lists(v))).bytes;
 }
 
 int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, void* project_state, void* scratch,
-                   int64_t scratch_bytes, gsplat_counts* counts_host, void* counts_event, void* stream_) {
-    (void)scratch; (void)scratch_bytes;
+                   int64_t scratch_bytes, gsplat_counts* counts_host, void* counts_event, int32_t flags, void* stream_) {
     bool fused = false;
     int rc = check_gaussians(g, &fused);
     if (rc) return rc;
     if ((rc = check_view(v))) return rc;
     if (!c2w || !project_state) return fail(GSPLAT_ERR_BAD_ARG, "c2w / project_state is NULL");
+    if (!scratch || scratch_bytes < (int64_t)sizeof(CounterBlock)) return fail(GSPLAT_ERR_WORKSPACE, "project scratch (counter block) too small");
+    if (reinterpret_cast<uintptr_t>(scratch) & 63u) return fail(GSPLAT_ERR_BAD_ARG, "project scratch must be 64-byte aligned");
     hipStream_t st = (hipStream_t)stream_;
     const int64_t n = g->n;
     const int64_t nl = n_lists(v), nb = n_bins(nl);
     ProjectState ps = carve_project(project_state, n > 0 ? n : 1, nl);
     const ViewK vk = make_viewk(*v);
-    hipLaunchKernelGGL(camera_kernel, dim3(1), dim3(256), 0, st, c2w, ps.cam, ps.counts, ps.shards, ps.bin_total, (int)nb);
-    LAUNCH_CHECK("camera_kernel");
+    const bool mapped = (flags & GSPLAT_PROJECT_COUNTS_MAPPED) != 0;
+    const bool colour_inside = !fused || (flags & GSPLAT_PROJECT_COLOUR_FUSED) != 0;
     if (n > 0) {
         Records out{ps.rec, ps.rect, ps.depth, ps.tiles, ps.mask, nullptr, nullptr};
-        if (fused)
-            hipLaunchKernelGGL((project_kernel<true, false>), dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, vk, out, ps.shards);
+        DevCounts* cm = mapped ? (DevCounts*)counts_host : nullptr;
+        CounterBlock* cb = (CounterBlock*)scratch;
+        const dim3 grid(blocks64(n)), block(64);
+        if (!fused)
+            hipLaunchKernelGGL((project_kernel<false, true>), grid, block, 0, st, *g, c2w, ps.cam, vk, out, cb, ps.counts, cm, ps.bin_total, (int)nb);
+        else if (colour_inside)
+            hipLaunchKernelGGL((project_kernel<true, true>), grid, block, 0, st, *g, c2w, ps.cam, vk, out, cb, ps.counts, cm, ps.bin_total, (int)nb);
         else
-            hipLaunchKernelGGL((project_kernel<false, true>), dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, vk, out, ps.shards);
+            hipLaunchKernelGGL((project_kernel<true, false>), grid, block, 0, st, *g, c2w, ps.cam, vk, out, cb, ps.counts, cm, ps.bin_total, (int)nb);
         LAUNCH_CHECK("project_kernel");
+        if (counts_host && !mapped) HIP_TRY(hipMemcpyAsync(counts_host, ps.counts, sizeof(gsplat_counts), hipMemcpyDeviceToHost, st));
+    } else {                        // no kernel runs: the counters are zero by definition
+        HIP_TRY(hipMemsetAsync(ps.counts, 0, sizeof(DevCounts), st));
+        HIP_TRY(hipMemsetAsync(ps.bin_total, 0, nb * sizeof(uint32_t), st));
+        if (counts_host) HIP_TRY(hipMemsetAsync(counts_host, 0, sizeof(gsplat_counts), st));
     }
-    hipLaunchKernelGGL(finish_counts_kernel, dim3(1), dim3(COUNT_SHARDS), 0, st, ps.shards, ps.counts);
-    LAUNCH_CHECK("finish_counts_kernel");
-    if (counts_host) HIP_TRY(hipMemcpyAsync(counts_host, ps.counts, sizeof(gsplat_counts), hipMemcpyDeviceToHost, st));
     if (counts_event) HIP_TRY(hipEventRecord((hipEvent_t)counts_event, st));
-    if (n > 0) {                    // these two need no pair buffer: they run while the host waits for the counters
+    if (n > 0) {                    // these need no pair buffer: queued behind the event, they run while a waiting host sizes the buffers
         hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)n_bin_blocks(n)), dim3(256), 0, st, n, ps.rect, ps.tiles, ps.mask, vk.lists_x, (int)nb,
                            ps.bin_total, ps.block_off, ps.list_count, ps.ranges, (int)nl);
         LAUNCH_CHECK("bin_count_kernel");
-        if (fused) {
+        if (!colour_inside) {
             hipLaunchKernelGGL(colour_kernel, dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, ps.tiles, ps.rec);
             LAUNCH_CHECK("colour_kernel");
         }
@@ -1610,11 +1740,12 @@ int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_vie
     return GSPLAT_OK;
 }
 
-int gsplat_bin(int64_t n, int64_t n_binned, const gsplat_view* v, const void* project_state, void* bin_state, void* scratch,
+int gsplat_bin(int64_t n, int64_t pair_capacity, const gsplat_view* v, const void* project_state, void* bin_state, void* scratch,
                int64_t scratch_bytes, void* stream_) {
     int rc = check_view(v);
     if (rc) return rc;
-    if (n < 0 || n_binned < 0 || n_binned > 0xFFFFFFFFLL) return fail(GSPLAT_ERR_BAD_ARG, "n / n_binned out of range");
+    const int64_t n_binned = pair_capacity;       // what the buffers hold; the actual count is read on the device (counts->n_binned)
+    if (n < 0 || n_binned < 0 || n_binned > 0xFFFFFFFFLL) return fail(GSPLAT_ERR_BAD_ARG, "n / pair_capacity out of range");
     if (!project_state || !bin_state) return fail(GSPLAT_ERR_BAD_ARG, "state is NULL");
     hipStream_t st = (hipStream_t)stream_;
     const ViewK vk = make_viewk(*v);
@@ -1633,10 +1764,10 @@ int gsplat_bin(int64_t n, int64_t n_binned, const gsplat_view* v, const void* pr
                        (int)nb, ps.bin_total, ps.block_off, ps.bin_start, (uint32_t)n_binned, sc.bvals);
     LAUNCH_CHECK("bin_scatter_kernel");
     hipLaunchKernelGGL(split_count_kernel, dim3((unsigned)n_chunks(n_binned)), dim3(256), 0, st, (int)nb, ps.bin_start, sc.bvals,
-                       (uint32_t)n_binned, ps.list_count, sc.seg_off);
+                       (uint32_t)n_binned, ps.counts, ps.list_count, sc.seg_off);
     LAUNCH_CHECK("split_count_kernel");
     hipLaunchKernelGGL(split_scatter_kernel, dim3((unsigned)n_chunks(n_binned)), dim3(256), 0, st, (int)nl, (int)nb, ps.bin_start, sc.bvals,
-                       (uint32_t)n_binned, ps.list_count, sc.seg_off, ps.ranges, sc.vals);
+                       (uint32_t)n_binned, ps.counts, ps.list_count, sc.seg_off, ps.ranges, sc.vals);
     LAUNCH_CHECK("split_scatter_kernel");
     hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, (int)nl, ps.ranges, ps.order, ps.class_bounds);
     LAUNCH_CHECK("plan_kernel");
@@ -1675,8 +1806,25 @@ int gsplat_rasterize_forward(int64_t n, int64_t n_binned, const gsplat_view* v, 
     return GSPLAT_OK;
 }
 
+namespace {
+struct DetScratch { float* part; uint32_t* pair_base; uint32_t* block_sum; int64_t bytes; };
+DetScratch carve_det(void* base, int64_t n, int64_t capacity) {
+    DetScratch d;
+    char* p = (char*)base;
+    int64_t o = 0;
+    d.part = (float*)(p + o); o += up((capacity > 0 ? capacity : 1) * 36);
+    d.pair_base = (uint32_t*)(p + o); o += up((n > 0 ? n : 1) * 4);
+    d.block_sum = (uint32_t*)(p + o); o += up(((n > 0 ? n : 1) + PB_BLOCK - 1) / PB_BLOCK * 4);
+    d.bytes = o;
+    return d;
+}
+}  // namespace
+
+int64_t gsplat_rasterize_backward_scratch_bytes(int64_t n, int64_t pair_capacity) { return carve_det(nullptr, n, pair_capacity).bytes; }
+
 int gsplat_rasterize_backward(int64_t n, int64_t n_binned, const gsplat_view* v, const void* project_state, const void* bin_state,
-                              const float* accum, const float* grad_image, float* grad2d, int32_t grad2d_zeroed, void* stream_) {
+                              const float* accum, const float* grad_image, float* grad2d, int32_t grad2d_zeroed,
+                              void* det_scratch, int64_t det_scratch_bytes, void* stream_) {
     int rc = check_view(v);
     if (rc) return rc;
     if (!project_state || !bin_state || !accum || !grad_image || !grad2d) return fail(GSPLAT_ERR_BAD_ARG, "NULL argument");
@@ -1684,12 +1832,35 @@ int gsplat_rasterize_backward(int64_t n, int64_t n_binned, const gsplat_view* v,
     const ViewK vk = make_viewk(*v);
     const int64_t nl = n_lists(v);
     ProjectState ps = carve_project((void*)project_state, n > 0 ? n : 1, nl);
-    if (!grad2d_zeroed) HIP_TRY(hipMemsetAsync(grad2d, 0, (size_t)(n > 0 ? n : 0) * 16 * sizeof(float), st));
-    if (n == 0 || n_binned == 0) return GSPLAT_OK;
-    hipLaunchKernelGGL(raster_backward_kernel, dim3((unsigned)nl), dim3(64), 0, st, ps.ranges, (const uint32_t*)bin_state, ps.rec,
+    const bool det = det_scratch != nullptr;
+    if (!grad2d_zeroed && !det) HIP_TRY(hipMemsetAsync(grad2d, 0, (size_t)(n > 0 ? n : 0) * 16 * sizeof(float), st));
+    if (n == 0) return GSPLAT_OK;
+    if (n_binned == 0) {
+        if (det) HIP_TRY(hipMemsetAsync(grad2d, 0, (size_t)n * 16 * sizeof(float), st));
+        return GSPLAT_OK;
+    }
+    if (!det) {
+        hipLaunchKernelGGL(raster_backward_kernel<false>, dim3((unsigned)nl), dim3(64), 0, st, ps.ranges, (const uint32_t*)bin_state, ps.rec,
+                           ps.order, vk.lists_x, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, accum, grad_image,
+                           grad2d, STATS_BWD, (uint32_t)(n - 1), DetArgs{});
+        LAUNCH_CHECK("raster_backward_kernel");
+        return GSPLAT_OK;
+    }
+    // deterministic: rows stored per (list, Gaussian) pair, then added per Gaussian in a fixed order
+    DetScratch ds = carve_det(det_scratch, n, n_binned);
+    if (ds.bytes > det_scratch_bytes) return fail(GSPLAT_ERR_WORKSPACE, "deterministic-backward scratch too small");
+    const unsigned pb_blocks = (unsigned)((n + PB_BLOCK - 1) / PB_BLOCK);
+    HIP_TRY(hipMemsetAsync(ds.part, 0, (size_t)n_binned * 36, st));          // rows of entries a saturated list never reaches
+    hipLaunchKernelGGL(tile_block_sum_kernel, dim3(pb_blocks), dim3(256), 0, st, n, ps.tiles, ds.block_sum);
+    LAUNCH_CHECK("tile_block_sum_kernel");
+    hipLaunchKernelGGL(pair_base_kernel, dim3(pb_blocks), dim3(256), 0, st, n, ps.tiles, ds.block_sum, ds.pair_base);
+    LAUNCH_CHECK("pair_base_kernel");
+    hipLaunchKernelGGL(raster_backward_kernel<true>, dim3((unsigned)nl), dim3(64), 0, st, ps.ranges, (const uint32_t*)bin_state, ps.rec,
                        ps.order, vk.lists_x, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, accum, grad_image,
-                       grad2d, STATS_BWD, (uint32_t)(n - 1));
-    LAUNCH_CHECK("raster_backward_kernel");
+                       grad2d, STATS_BWD, (uint32_t)(n - 1), DetArgs{ps.rect, ps.mask, ps.tiles, ds.pair_base, ds.part, (uint32_t)n_binned});
+    LAUNCH_CHECK("raster_backward_kernel<deterministic>");
+    hipLaunchKernelGGL(pair_reduce_kernel, dim3(blocks256(n)), dim3(256), 0, st, n, ps.tiles, ds.pair_base, ds.part, (uint32_t)n_binned, grad2d);
+    LAUNCH_CHECK("pair_reduce_kernel");
     return GSPLAT_OK;
 }
 

@@ -46,6 +46,16 @@ def agree_on_views(n_local, group=None, views_per_rank=None, device=None):
     return all(c == counts[0] for c in counts), int(sum(counts))
 
 
+def any_rank(flag, group=None, device=None):
+    """Logical OR of a host-side flag over the ranks (one tiny all-reduce; the caller has just synchronised anyway)."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return int(bool(flag))
+    on_gpu = dist.get_backend(group) != "gloo"
+    t = torch.tensor([int(bool(flag))], dtype=torch.int32, device=device if on_gpu and device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
+
+
 def _big_and_small(grads):
     """Split a list of gradient tensors into the largest (sent in place) and the rest (flattened together)."""
     order = sorted(range(len(grads)), key=lambda i: grads[i].numel(), reverse=True)
@@ -217,6 +227,13 @@ class FactoredExchange:
         from . import ops
         ops.set_sh_gradient_sink(None)
         return False
+
+    def abandon(self):
+        """Drop what was collected (the pass is being repeated): collectives already in flight are waited for, nothing is kept."""
+        for _, _, works in self._early:
+            for w in works[:2]:
+                w.wait()
+        self.logits, self.eyes, self._early = [], [], []
 
     def finish(self):
         p = self.params

@@ -48,27 +48,69 @@ def _f32(t, shape, name):
     return t
 
 
+class PairCapacityExceeded(RuntimeError):
+    """A frame rendered without waiting for its pair count (deferred_checks) had more (list, Gaussian) pairs than the buffers
+    kept from earlier frames: its image and gradients are invalid.  The capacity has been raised; render it again."""
+
+
+PINNED_SLOTS = 256      # counter blocks in flight per (device, stream) before one is reused
+
+
 class _Workspace:
-    """Grow-only scratch buffers, one pinned counter block and one event per (device, stream): calls on different streams
-    never share them (scratch is dead after each call, in stream order)."""
+    """Grow-only scratch buffers, the persistent counter block of gsplat_project, a ring of pinned counter blocks and one
+    event per (device, stream): calls on different streams never share them (scratch is dead after each call, in stream
+    order).  `capacity`: per device, the largest pair count seen x 1.25 (sizes the buffers of frames that do not wait)."""
 
     def __init__(self):
         self.scratch = {}
         self.pinned = {}
         self.events = {}
+        self.counters = {}
+        self.capacity = {}
+        self.slot = {}
+
+    def get_counter_block(self, device, nbytes):
+        """Zeroed once; every gsplat_project call leaves it zeroed again (include/gsplat_mi355x.h)."""
+        key = self._key(device)
+        buf = self.counters.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
+            self.counters[key] = buf
+        return buf
+
+    def next_pinned(self, device):
+        """A pinned, device-mapped counter block nobody else is using for the next PINNED_SLOTS calls on this stream."""
+        key = self._key(device)
+        ring = self.pinned.get(key)
+        if ring is None:
+            ring = self.pinned[key] = torch.zeros((PINNED_SLOTS, C.sizeof(_abi.Counts)), dtype=torch.uint8).pin_memory()
+        i = self.slot.get(key, 0)
+        self.slot[key] = (i + 1) % PINNED_SLOTS
+        return ring[i]
+
+    def note_pairs(self, device, n_binned):
+        key = (device.type, device.index)
+        want = int(n_binned * 1.25) + 4096
+        if want > self.capacity.get(key, 0):
+            self.capacity[key] = want
+
+    def pair_capacity(self, device):
+        return self.capacity.get((device.type, device.index), 0)
 
     @staticmethod
     def _key(device):
         return (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
 
-    def get_event(self, device):
-        """One reusable event per stream: gsplat_project records it right behind the copy of the counters."""
+    def get_event(self, device, fresh=False):
+        """One reusable event per stream: gsplat_project records it right behind the counters (fresh: an event of its own,
+        for a frame whose counters are read later)."""
         key = self._key(device)
-        ev = self.events.get(key)
+        ev = None if fresh else self.events.get(key)
         if ev is None:
             ev = torch.cuda.Event(enable_timing=False, blocking=False)
             ev.record(torch.cuda.current_stream(device))          # events are created lazily: force the handle to exist
-            self.events[key] = ev
+            if not fresh:
+                self.events[key] = ev
         return ev
 
     def get_scratch(self, device, nbytes):
@@ -79,13 +121,6 @@ class _Workspace:
             self.scratch[key] = buf
         return buf
 
-    def get_pinned(self, device):
-        key = self._key(device)
-        buf = self.pinned.get(key)
-        if buf is None:
-            buf = torch.zeros(C.sizeof(_abi.Counts), dtype=torch.uint8).pin_memory()
-            self.pinned[key] = buf
-        return buf
 
 
 _ws = _Workspace()
@@ -139,6 +174,60 @@ class _stage:
         return False
 
 
+class DeferredChecks:
+    """Render without waiting for the per-frame counters (training loops, frame sequences):
+
+        with ops.deferred_checks() as chk:
+            for view in views: loss(render_gaussians(...)).backward()      # no host synchronisation per view
+        chk.verify()                                                        # ONE wait, then every frame's checks
+
+    Inside the block a render sizes its pair buffers from the capacity kept from earlier frames (x 1.25 of the largest
+    count seen on the device) instead of waiting for its own count, and the SH colour is evaluated inside the projection
+    kernel (one pass over the inputs).  What the reference decides from the counts is decided in verify(): survivors but
+    none on screen -> the same Exception("All projected points are off-screen"), now raised there; no survivor -> the frame
+    was a zero image with zero gradients anyway.  A frame with more pairs than the capacity raises PairCapacityExceeded
+    (capacity raised; render the block again: its results are invalid).  The first render on a device (no capacity known
+    yet) waits like an ordinary one."""
+
+    def __init__(self):
+        self.pending = []          # (pinned counter block, event, capacity, device)
+        self.counts = []
+
+    def __enter__(self):
+        _deferred_stack.append(self)
+        return self
+
+    def __exit__(self, *exc):
+        _deferred_stack.remove(self)
+        return False
+
+    def verify(self):
+        global _last_counts
+        pending, self.pending = self.pending, []
+        overflow, offscreen = False, False
+        for pinned, ev, cap, dev in pending:
+            ev.synchronize()
+            counts = _abi.Counts.from_buffer_copy(pinned.numpy().tobytes())
+            self.counts.append(counts)
+            _ws.note_pairs(dev, counts.n_binned)
+            overflow |= cap is not None and counts.n_binned > cap
+            offscreen |= _abi.lib().gsplat_classify_counts(C.byref(counts)) == _abi.GSPLAT_SCENE_ALL_OFFSCREEN
+            _last_counts = (counts.n_survivors, counts.n_visible, int(counts.n_pairs))
+        if offscreen:
+            raise Exception(OFFSCREEN_MSG)
+        if overflow:
+            raise PairCapacityExceeded("more (list, Gaussian) pairs than the buffers kept from earlier frames: render the block again")
+        return self.counts
+
+
+_deferred_stack = []
+forward_modes = {"waited": 0, "deferred": 0}     # forward passes that waited for their counters / that did not (diagnostics, tests)
+
+
+def deferred_checks():
+    return DeferredChecks()
+
+
 def _make_gaussians(n, pos, opacity_raw, color=None, sigma=None, scale_raw=None, q_raw=None, f_dc=None, f_rest=None):
     return _abi.Gaussians(n, _p(pos), _p(opacity_raw), _p(color), _p(sigma), _p(scale_raw), _p(q_raw), _p(f_dc), _p(f_rest))
 
@@ -150,12 +239,13 @@ class _Frame:
 
 class _Pending:
     """A forward call between its two halves: projection queued, counters not read yet."""
-    __slots__ = ("frame", "gaussians", "pinned", "ready", "device", "stream")
+    __slots__ = ("frame", "gaussians", "pinned", "ready", "device", "stream", "capacity")
 
 
 def _forward_begin(fused, view, c2w, pos, opacity_raw, a, b, c, d):
     """First half of the forward pass: everything up to (not including) the host's wait for the counters.  Returns
-    (pending, None), or (None, result) when there is nothing to wait for (zero Gaussians)."""
+    (pending, None), or (None, result) when there is nothing to wait for (zero Gaussians).  Inside a deferred_checks()
+    block (and once a pair capacity is known for the device) the second half will not wait: pending.capacity is set."""
     lib = _abi.lib()
     dev = pos.device
     n = pos.shape[0]
@@ -179,13 +269,18 @@ def _forward_begin(fused, view, c2w, pos, opacity_raw, a, b, c, d):
     with torch.cuda.device(dev):
         pend.stream = torch.cuda.current_stream(dev)
         fr.proj_state = torch.empty(lib.gsplat_project_state_bytes(n, C.byref(view)), dtype=torch.uint8, device=dev)
-        scratch = _ws.get_scratch(dev, lib.gsplat_project_scratch_bytes(n))
-        pend.pinned = _ws.get_pinned(dev)
-        pend.ready = _ws.get_event(dev)
+        counters = _ws.get_counter_block(dev, lib.gsplat_project_scratch_bytes(n))
+        deferred = bool(_deferred_stack) and _ws.pair_capacity(dev) > 0
+        pend.capacity = _ws.pair_capacity(dev) if deferred else None
+        pend.pinned = _ws.next_pinned(dev)
+        pend.ready = _ws.get_event(dev, fresh=deferred)
+        # the counters go straight into the pinned block (mapped into the device's address space: no copy operation);
+        # a frame that will not wait for them evaluates the SH colour inside the projection kernel
+        flags = _abi.GSPLAT_PROJECT_COUNTS_MAPPED | (_abi.GSPLAT_PROJECT_COLOUR_FUSED if deferred else 0)
         with _stage("project"):
-            _abi.check(lib.gsplat_project(C.byref(g), _p(c2w32), C.byref(view), _p(fr.proj_state), _p(scratch),
-                                          scratch.numel(), C.c_void_p(pend.pinned.data_ptr()), C.c_void_p(pend.ready.cuda_event),
-                                          _stream_ptr(dev)), "gsplat_project")
+            _abi.check(lib.gsplat_project(C.byref(g), _p(c2w32), C.byref(view), _p(fr.proj_state), _p(counters),
+                                          counters.numel(), C.c_void_p(pend.pinned.data_ptr()), C.c_void_p(pend.ready.cuda_event),
+                                          flags, _stream_ptr(dev)), "gsplat_project")
     return pend, None
 
 
@@ -201,17 +296,27 @@ def _forward_end(pend, need_grad):
         # the one host wait of the forward pass: the pair count sizes the binning buffers, and the reference's empty /
         # off-screen conventions need the survivor counts.  Only the counters are waited for: the first binning kernel and
         # (fused inputs) the SH colour pass are queued behind them and run during this round trip.
-        pend.ready.synchronize()
-        counts = _abi.Counts.from_buffer_copy(pend.pinned.numpy().tobytes())
-        scene = lib.gsplat_classify_counts(C.byref(counts))
-        if scene == _abi.GSPLAT_SCENE_ALL_OFFSCREEN:
-            raise Exception(OFFSCREEN_MSG)
         image = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
-        if scene == _abi.GSPLAT_SCENE_ALL_CULLED:
-            fr.empty = True
-            fr.proj_state = None
-            return image.zero_(), fr, counts
-        fr.n_pairs = int(counts.n_binned)            # pairs actually binned (half-tile lists); counts.n_pairs = the reference's P
+        if pend.capacity is not None:
+            # deferred: no wait.  Buffers of the capacity kept from earlier frames; the kernels read the real count on the
+            # device; the host looks at the counters in DeferredChecks.verify()
+            counts = None
+            fr.n_pairs = int(pend.capacity)
+            forward_modes["deferred"] += 1
+            _deferred_stack[-1].pending.append((pend.pinned, pend.ready, fr.n_pairs, dev))
+        else:
+            pend.ready.synchronize()
+            forward_modes["waited"] += 1
+            counts = _abi.Counts.from_buffer_copy(pend.pinned.numpy().tobytes())
+            _ws.note_pairs(dev, counts.n_binned)
+            scene = lib.gsplat_classify_counts(C.byref(counts))
+            if scene == _abi.GSPLAT_SCENE_ALL_OFFSCREEN:
+                raise Exception(OFFSCREEN_MSG)
+            if scene == _abi.GSPLAT_SCENE_ALL_CULLED:
+                fr.empty = True
+                fr.proj_state = None
+                return image.zero_(), fr, counts
+            fr.n_pairs = int(counts.n_binned)        # pairs actually binned (16 x 8 lists); counts.n_pairs = the reference's P
         fr.bin_state = torch.empty(lib.gsplat_bin_state_bytes(fr.n_pairs, C.byref(view)), dtype=torch.uint8, device=dev)
         scratch = _ws.get_scratch(dev, lib.gsplat_bin_scratch_bytes(fr.n_pairs, C.byref(view)))
         with _stage("bin"):
@@ -249,6 +354,16 @@ def _flat_like(ins):
 # the render backward of the fused entry hands the 3 colour-logit gradients per Gaussian to the sink instead of
 # computing the 48 SH-coefficient gradients, and returns no gradient for f_dc / f_rest.
 _sh_sink = None
+_deterministic = False
+
+
+def set_deterministic(flag=True):
+    """Bitwise reproducible gradients: the raster backward stores its per-(list, Gaussian) sums and adds them per Gaussian in a
+    fixed order instead of using float atomics (whose order of arrival changes the last bits from run to run).  Slower by the
+    cost of a 36-byte row per pair written and read once.  Returns the previous setting."""
+    global _deterministic
+    old, _deterministic = _deterministic, bool(flag)
+    return old
 
 
 def set_sh_gradient_sink(sink):
@@ -276,9 +391,13 @@ def _backward_impl(fr, grad_image):
         zeroed = fr.grad2d is not None
         grad2d = fr.grad2d if zeroed else torch.empty((fr.n, 16), dtype=torch.float32, device=dev)
         fr.grad2d = None                       # a second backward through the same graph must not reuse a dirty buffer
+        det = None
+        if _deterministic:
+            det = _ws.get_scratch(dev, lib.gsplat_rasterize_backward_scratch_bytes(fr.n, fr.n_pairs))
         with _stage("raster_backward"):
             _abi.check(lib.gsplat_rasterize_backward(fr.n, fr.n_pairs, C.byref(fr.view), _p(fr.proj_state), _p(fr.bin_state),
-                                                     _p(fr.accum), _p(gi), _p(grad2d), int(zeroed), st), "gsplat_rasterize_backward")
+                                                     _p(fr.accum), _p(gi), _p(grad2d), int(zeroed), _p(det),
+                                                     det.numel() if det is not None else 0, st), "gsplat_rasterize_backward")
         if factored:
             # logit gradients first: the sink may start exchanging them while the projection backward runs
             glogit = torch.empty((fr.n, 3), dtype=torch.float32, device=dev)
@@ -325,7 +444,8 @@ class _RenderFn(torch.autograd.Function):
         ctx.dtypes = [t.dtype if isinstance(t, torch.Tensor) else None for t in (pos, opacity_raw, a, b, c, d)]
         ctx.opa_shape = opacity_raw.shape
         global _last_counts
-        ctx.counts = _last_counts = (counts.n_survivors, counts.n_visible, int(counts.n_pairs))
+        if counts is not None:                   # (a deferred frame's counters are read in DeferredChecks.verify())
+            ctx.counts = _last_counts = (counts.n_survivors, counts.n_visible, int(counts.n_pairs))
         return image if pos.dtype == torch.float32 else image.to(pos.dtype)
 
     @staticmethod

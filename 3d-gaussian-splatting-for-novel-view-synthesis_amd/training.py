@@ -97,21 +97,38 @@ class Trainer:
         pos_lr = optim.position_lr(iteration, c.position_lr_init, c.position_lr_final, c.position_lr_delay_mult,
                                    c.position_lr_max_steps)
         self.optimizer.param_groups[0]['lr'] = pos_lr
-        self.optimizer.zero_grad()
-        acc = torch.zeros(3, dtype=torch.float32, device=dev)
-        # data parallel: SH gradients travel in factored form (dp.FactoredExchange, 2.6x fewer bytes over xGMI at 8 views)
-        exchange = dp.FactoredExchange(m.get_params(), world_views=1, group=self.group, equal_views=even) if world > 1 else None
-        with (exchange if exchange is not None else contextlib.nullcontext()):       # the gradient sink is always removed again
-            for v in views:
-                image_gt = torch.as_tensor(v['image']).to(dev)
-                c2w = torch.as_tensor(v['c2w'], dtype=torch.float32).to(dev)
-                rendered = ops.render_gaussians(m.pos, m.f_dc, m.f_rest, m.opacity_raw, m.scale_raw, m.q_raw, c2w,
-                                                int(v['H']), int(v['W']), float(v['fx']), float(v['fy']), float(v['cx']), float(v['cy']))
-                loss, vals = losses.compute_loss_device(rendered, image_gt, c.lambda_l1, c.lambda_ssim)
-                (loss / n_global).backward()
-                acc += vals / n_global
-        if exchange is not None:
-            exchange.finish()                 # the loss was already divided by the global batch: world_views = 1
+        for attempt in range(4):
+            self.optimizer.zero_grad()
+            acc = torch.zeros(3, dtype=torch.float32, device=dev)
+            # data parallel: SH gradients travel in factored form (dp.FactoredExchange, 2.6x fewer bytes over xGMI at 8 views)
+            exchange = dp.FactoredExchange(m.get_params(), world_views=1, group=self.group, equal_views=even) if world > 1 else None
+            # no host synchronisation per view: the renders size their buffers from earlier frames, the per-frame checks
+            # (off-screen exception, buffer capacity) are made ONCE, after the last backward is queued
+            with ops.deferred_checks() as checks, (exchange if exchange is not None else contextlib.nullcontext()):
+                for v in views:                                                        # (the gradient sink is always removed again)
+                    image_gt = torch.as_tensor(v['image']).to(dev)
+                    c2w = torch.as_tensor(v['c2w'], dtype=torch.float32).to(dev)
+                    rendered = ops.render_gaussians(m.pos, m.f_dc, m.f_rest, m.opacity_raw, m.scale_raw, m.q_raw, c2w,
+                                                    int(v['H']), int(v['W']), float(v['fx']), float(v['fy']), float(v['cx']), float(v['cy']))
+                    loss, vals = losses.compute_loss_device(rendered, image_gt, c.lambda_l1, c.lambda_ssim)
+                    (loss / n_global).backward()
+                    acc += vals / n_global
+            redo = 0
+            try:
+                checks.verify()
+            except ops.PairCapacityExceeded:
+                redo = 1                          # a view outgrew the buffers: this pass's gradients are invalid (capacity now raised)
+            if world > 1:                         # every rank repeats the pass or none does (the collectives must match)
+                redo = dp.any_rank(redo, self.group, device=dev)
+            if exchange is not None:
+                if redo:
+                    exchange.abandon()
+                else:
+                    exchange.finish()             # the loss was already divided by the global batch: world_views = 1
+            if not redo:
+                break
+        else:
+            raise RuntimeError("the pair buffers overflowed four times in a row")
         names = dp.PARAM_NAMES
         for k in names:
             p = getattr(m, k)

@@ -237,6 +237,8 @@ def main():
                     help="N > 1: SH gradients as logit gradients + local rebuild (DESIGN.md §7), or one all-reduce of all six tensors")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--launch-check", action="store_true", help="only check the rank launch + process group (no GPU needed)")
+    ap.add_argument("--wait-counts", action="store_true", help="every forward pass waits for its pair count (exact buffers) instead of "
+                    "sizing them from earlier frames (ops.deferred_checks)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -290,28 +292,44 @@ def main():
 
     info = {"allreduce": None}
 
+    import contextlib
+
+    def checks():
+        # the way training.Trainer.step renders: no wait for the frame's pair count (buffers sized from earlier frames, SH colour
+        # inside the projection kernel); the frame's checks (off-screen exception, buffer capacity) are made by verify() below,
+        # inside the step.  --wait-counts: the reference-style call that waits for the counters in the middle of the forward pass.
+        return contextlib.nullcontext() if args.wait_counts else ops.deferred_checks()
+
     def local_step():
-        if need_grad:
-            for p in params.values():
-                p.grad = None
-            gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args).backward(gimg)
-        else:
-            with torch.no_grad():
-                gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args)
+        with checks() as chk:
+            if need_grad:
+                for p in params.values():
+                    p.grad = None
+                gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args).backward(gimg)
+            else:
+                with torch.no_grad():
+                    gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args)
+        if chk is not None:
+            chk.verify()
 
     def step():
         if not need_grad or world == 1:
             return local_step()
         for p in params.values():
             p.grad = None
-        if args.exchange == "factored":
-            with dp.FactoredExchange(params, world_views=world) as ex:
+        with checks() as chk:
+            if args.exchange == "factored":
+                with dp.FactoredExchange(params, world_views=world) as ex:
+                    gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args).backward(gimg)
+            else:
                 gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args).backward(gimg)
+        if chk is not None:
+            chk.verify()
+        if args.exchange == "factored":
             ex.finish()
             info["allreduce"] = "factored: all-reduce of pos/opacity/scale/rotation gradients (44 B per Gaussian) + all-gather " \
                                 "of colour-logit gradients (12 B per Gaussian and view) + local SH rebuild"
         else:
-            gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args).backward(gimg)
             grads = [params[k].grad for k in NAMES]
             info["allreduce"] = "one flat buffer, single collective" if dp._common_base(grads) is not None else "2 buckets"
             dp.allreduce_gradients(grads, world_views=world)
@@ -417,7 +435,9 @@ def main():
                                    f"{'forward+backward' if need_grad else 'forward only'}, one camera view per GPU per step"
                                    + (", gradient exchange over RCCL" if world > 1 and need_grad else ""),
                        "N": N, "V": V, "P": P, "tiles": math.ceil(H / 16) * math.ceil(W / 16),
-                       "parallelism": f"dp{world} by camera view", "allreduce": info["allreduce"]},
+                       "parallelism": f"dp{world} by camera view", "allreduce": info["allreduce"],
+                       "counts": "waited for in every forward pass" if args.wait_counts else
+                                 "not waited for: buffers from earlier frames, checks once per step (ops.deferred_checks, as Trainer.step)"},
             "fps": world * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(KERNEL_OF_STAGE[dom]), "kernel": KERNEL_OF_STAGE[dom],
@@ -493,7 +513,9 @@ def single_gpu_extras(gs, ops, params, cam, cam_args, dev, fence):
         def step5():
             for p in p5.values():
                 p.grad = None
-            gs.render_gaussians(*[p5[k] for k in NAMES], eye, *a5).backward(g5)
+            with ops.deferred_checks() as chk:
+                gs.render_gaussians(*[p5[k] for k in NAMES], eye, *a5).backward(g5)
+            chk.verify()
         for _ in range(2):
             step5()
         _, V5, P5 = gs.render_stats()

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GSPLAT_ABI_VERSION 2
+#define GSPLAT_ABI_VERSION 3
 
 /* call status */
 #define GSPLAT_OK 0
@@ -56,7 +56,8 @@ typedef struct gsplat_view {
     float fx, fy, cx, cy;         /* pinhole intrinsics (pixels)                                     */
     float near_z, far_z;          /* near=0.01, far=100.0                                            */
     float pix_guard;              /* 32                                                              */
-    int32_t tile;                 /* T=16 (the only tile size the HIP kernels are built for)         */
+    int32_t tile;                 /* T=16; any T >= 1 (it sets the reference's tile rectangles = the
+                                     reported pair count; the image does not depend on it)            */
     float min_conis;              /* 1e-6                                                            */
     float chi_square_clip;        /* 6.25                                                            */
     float alpha_max;              /* 0.99                                                            */
@@ -99,8 +100,8 @@ typedef struct gsplat_counts {
     int64_t n_pairs;       /* the reference's (tile, Gaussian) pairs, F11  (P of SURVEY.md)          */
     int32_t max_tiles_per_gaussian;   /* of the binned rectangles                                    */
     int32_t reserved;
-    int64_t n_binned;      /* (half-tile list, Gaussian) pairs actually binned: the tight box of each
-                              Gaussian over 16 x 8-pixel lists; sizes the gsplat_bin buffers          */
+    int64_t n_binned;      /* (list, Gaussian) pairs actually binned: the ellipse of each Gaussian over
+                              16 x 8-pixel lists; sizes the gsplat_bin buffers                        */
 } gsplat_counts;
 
 int gsplat_abi_version(void);
@@ -109,46 +110,68 @@ int gsplat_classify_counts(const gsplat_counts* counts_host);
 
 /* ---- buffer sizes (bytes) ---------------------------------------------------------------------- */
 int64_t gsplat_project_state_bytes(int64_t n, const gsplat_view* v);    /* kept until the backward pass */
-int64_t gsplat_project_scratch_bytes(int64_t n);                        /* free after gsplat_project    */
-int64_t gsplat_bin_state_bytes(int64_t n_binned, const gsplat_view* v); /* kept until the backward pass */
-int64_t gsplat_bin_scratch_bytes(int64_t n_binned, const gsplat_view* v); /* free after gsplat_bin      */
+int64_t gsplat_project_scratch_bytes(int64_t n);     /* persistent counter block of gsplat_project: see there         */
+int64_t gsplat_bin_state_bytes(int64_t pair_capacity, const gsplat_view* v);   /* kept until the backward pass   */
+int64_t gsplat_bin_scratch_bytes(int64_t pair_capacity, const gsplat_view* v); /* free after gsplat_bin          */
 
 /* ---- forward ----------------------------------------------------------------------------------- */
 /* F1-F8, F10, F13 (+F2, F3 when fused): per-Gaussian projection, culls, EWA covariance, eigen clamp,
- * conic, rectangle and mask of half-tile lists, colour; counts the (list, Gaussian) pairs in total and
- * per coarse bin.  At most 2^26 Gaussians per call.  c2w is the DEVICE [4,4] row-major camera-to-world matrix (no host read ->
- * no synchronisation).  If counts_host is not NULL the counters are copied there with hipMemcpyAsync
- * on `stream`, and counts_event (a hipEvent_t, nullable) is recorded right behind that copy: the caller
- * waits for the event (or synchronises the stream) before reading them -- it needs n_binned to size
- * the gsplat_bin buffers.  The first binning kernel and (fused inputs) the SH colour pass are queued
- * BEHIND the event, so waiting on the event rather than the stream lets them run during the host's
- * round trip.                                                                                          */
+ * conic, rectangle and mask of 16 x 8-pixel lists, colour; counts the (list, Gaussian) pairs in total and
+ * per coarse bin.  At most 2^26 Gaussians per call.  c2w is the DEVICE [4,4] row-major camera-to-world matrix (no
+ * host read -> no synchronisation).
+ *   scratch        gsplat_project_scratch_bytes() bytes, 64-byte aligned: a block of counters that must be ZERO when
+ *                  the call starts.  Zero it once after allocating it; every call leaves it zeroed again (the last wave
+ *                  of the projection kernel adds the counters up and clears them: no clearing or totals kernel).  One
+ *                  block per stream; calls sharing a block must be stream-ordered.
+ *   counts_host    (nullable) receives the counters: by hipMemcpyAsync on `stream`, or -- flag
+ *                  GSPLAT_PROJECT_COUNTS_MAPPED: it is device-accessible pinned host memory (hipHostMalloc) -- stored by
+ *                  the kernel itself (one stream operation less).
+ *   counts_event   (hipEvent_t, nullable) recorded right behind the counters: a caller that wants exact buffer sizes
+ *                  waits for it (not for the stream: the first binning kernel and, without COLOUR_FUSED, the SH colour
+ *                  pass are queued BEHIND the event and run during the host's round trip) and reads n_binned.
+ *   flags          GSPLAT_PROJECT_COLOUR_FUSED: evaluate the SH colour inside the projection kernel (one pass over the
+ *                  inputs: best when the host does NOT wait for the counters -- see gsplat_bin's pair_capacity).      */
+#define GSPLAT_PROJECT_COLOUR_FUSED 1
+#define GSPLAT_PROJECT_COUNTS_MAPPED 2
 int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, void* project_state,
-                   void* scratch, int64_t scratch_bytes, gsplat_counts* counts_host, void* counts_event,
+                   void* scratch, int64_t scratch_bytes, gsplat_counts* counts_host, void* counts_event, int32_t flags,
                    void* stream);
 
 /* F9, F11, F12: every Gaussian is appended to the lists of its rectangle (two-level counting sort),
  * the lists get their [start, end) and a longest-first launch order, and every list is sorted; the
  * order inside a list is (camera depth, Gaussian index) ascending.  The rendered image does not
- * depend on the binning granularity, only on that order.                              */
-int gsplat_bin(int64_t n, int64_t n_binned, const gsplat_view* v, const void* project_state, void* bin_state,
+ * depend on the binning granularity, only on that order.
+ *   pair_capacity  pairs the bin_state / scratch buffers were sized for (gsplat_bin_*_bytes).  The number of pairs
+ *                  really binned is read on the DEVICE (the counters gsplat_project left in project_state), so the
+ *                  host may pass the exact n_binned it waited for, or -- without ever synchronising -- a capacity kept
+ *                  from earlier frames.  If the frame has more pairs than that, nothing is written out of bounds, the
+ *                  frame's image and gradients are garbage, and the caller finds n_binned > pair_capacity in the
+ *                  counters whenever it reads them: it then renders the frame again with larger buffers.
+ *                  At most 2^32 - 1 pairs; images up to 8192 coarse bins (64 lists each: 8192 x 8192 pixels).          */
+int gsplat_bin(int64_t n, int64_t pair_capacity, const gsplat_view* v, const void* project_state, void* bin_state,
                void* scratch, int64_t scratch_bytes, void* stream);
 
 /* F14, F15: per-tile front-to-back compositing.  image[H,W,3] receives clamp(C,0,1); accum[H,W,3]
  * (nullable; required for the backward pass) receives the unclamped C.  grad2d (nullable, [n,16]
  * floats): cleared here for the coming gsplat_rasterize_backward (pass grad2d_zeroed = 1 there), which
  * saves that call a 64-byte-per-Gaussian fill; only worth it when n / lists is small (<= 256).          */
-int gsplat_rasterize_forward(int64_t n, int64_t n_binned, const gsplat_view* v, const void* project_state,
+int gsplat_rasterize_forward(int64_t n, int64_t pair_capacity, const gsplat_view* v, const void* project_state,
                              const void* bin_state, float* image, float* accum, float* grad2d, void* stream);
 
 /* ---- backward ---------------------------------------------------------------------------------- */
 /* B1: gradient of the compositing w.r.t. the per-Gaussian 2D quantities.  grad2d is [n,16] floats, private to the
  * library (moments of dL/dq over the pixels for the centre and the conic, then opacity, r, g, b, padding); it is zeroed
  * by this call before accumulation (unless grad2d_zeroed: gsplat_rasterize_forward already cleared it) and consumed
- * by gsplat_project_backward.                                                                                        */
-int gsplat_rasterize_backward(int64_t n, int64_t n_binned, const gsplat_view* v, const void* project_state,
+ * by gsplat_project_backward.
+ *   det_scratch    NULL: the per-(list, Gaussian) sums are added into grad2d with float atomics (fastest; the order of the
+ *                  additions, hence the last bits of the gradients, varies from run to run).  Not NULL
+ *                  (gsplat_rasterize_backward_scratch_bytes(n, pair_capacity) bytes): DETERMINISTIC mode -- the sums are
+ *                  stored per pair and added per Gaussian in a fixed order: gradients are bitwise reproducible.            */
+int64_t gsplat_rasterize_backward_scratch_bytes(int64_t n, int64_t pair_capacity);
+int gsplat_rasterize_backward(int64_t n, int64_t pair_capacity, const gsplat_view* v, const void* project_state,
                               const void* bin_state, const float* accum, const float* grad_image,
-                              float* grad2d, int32_t grad2d_zeroed, void* stream);
+                              float* grad2d, int32_t grad2d_zeroed, void* det_scratch, int64_t det_scratch_bytes,
+                              void* stream);
 
 /* B2 (+B3 when fused): chain the 2D gradients back to the inputs of gsplat_project.
  * Factored form (fused inputs; out->f_dc and out->f_rest NULL): instead of the 48 SH-coefficient

@@ -113,9 +113,7 @@ def test_config3_full_n_gradients_vs_oracle_on_a_window(gs, cal3):
         util.check_grad(p[k].grad.cpu().numpy(), cal3["g64"][k], k, cal=cal3["g32"][k])
 
 
-def test_config3_backward_is_reproducible_to_rounding(gs):
-    """Float atomics make the summation order vary between runs: results must agree to rounding."""
-    _, p, cam = _scene(3, grad=True)
+def _two_backward_runs(gs, p, cam):
     gimg = torch.rand(cam[0], cam[1], 3, generator=torch.Generator().manual_seed(1)).to(DEV)
     grads = []
     for _ in range(2):
@@ -123,10 +121,32 @@ def test_config3_backward_is_reproducible_to_rounding(gs):
             t.grad = None
         gs.render_gaussians(*[p[k] for k in NAMES], torch.eye(4, device=DEV), *cam).backward(gimg)
         grads.append({k: p[k].grad.clone() for k in NAMES})
+    return grads
+
+
+def test_config3_backward_is_reproducible_to_rounding(gs):
+    """Default mode: float atomics make the summation order vary between runs: results must agree to rounding."""
+    _, p, cam = _scene(3, grad=True)
+    grads = _two_backward_runs(gs, p, cam)
     for k in NAMES:
         a, b = grads[0][k], grads[1][k]
         assert torch.isfinite(a).all()
         assert float((a - b).norm() / (a.norm() + 1e-30)) < 1e-5, k
+
+
+def test_config3_deterministic_backward_is_bitwise_reproducible(gs):
+    """gs.set_deterministic(True): per-(list, Gaussian) sums stored and added per Gaussian in a fixed order -- two runs are
+    torch.equal, and the gradients are those of the default mode up to summation order."""
+    _, p, cam = _scene(3, grad=True)
+    ref = _two_backward_runs(gs, p, cam)[0]
+    old = gs.set_deterministic(True)
+    try:
+        grads = _two_backward_runs(gs, p, cam)
+    finally:
+        gs.set_deterministic(old)
+    for k in NAMES:
+        assert torch.equal(grads[0][k], grads[1][k]), k
+        assert float((grads[0][k] - ref[k]).norm() / (ref[k].norm() + 1e-30)) < 1e-5, k
 
 
 @pytest.mark.parametrize("cfg,counts", [(2, (95_500, 304_466)), (3, (973_068, 2_720_508))])

@@ -68,7 +68,9 @@ def check_image(img, ref, cal=None, what="image", flip=IMG_TOL_FLIP, frac=None):
     assert np.isfinite(img).all(), f"{what}: non-finite values"
     e = image_errors(img, ref)
     c = cal if isinstance(cal, dict) or cal is None else image_errors(cal, ref)
-    allowed_bad = max(1.0 - (IMG_BULK_FRAC if frac is None else frac), K_CAL * c["bad"] if c else 0.0)
+    # (+ 3 values = ONE pixel when a calibration is given: a single flipped pixel where the fp32 reference happens to have none is
+    # a Poisson event of this small a count, not a defect -- small images have fewer than 10^4 pixels)
+    allowed_bad = max(1.0 - (IMG_BULK_FRAC if frac is None else frac), K_CAL * c["bad"] if c else 0.0) + (3.0 / img.size if c else 0.0)
     # values beyond 5e-3 are threshold flips: as many as K_CAL x the calibration's (+2: they are rare events), none without one
     n_cal_big = c["big"] * img.size / c["n"] if c else 0          # (a calibration measured on a window of the scene is scaled to the frame)
     allowed_big = int(np.ceil(K_CAL * n_cal_big)) + (2 if c else 0)
