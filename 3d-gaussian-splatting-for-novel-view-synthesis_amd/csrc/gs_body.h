@@ -147,9 +147,10 @@ GS_HD RecOut project_core(const GaussIn& in, bool fused, Coef coef, const Camera
 // K8 core.  r9 = (g_u, g_v, g_A11, g_A12, g_A22, g_opacity, g_r, g_g, g_b) of a visible Gaussian.
 // emit_sh(k, ch, val) receives dL/d(SH coefficient) for k = 0..15 (k = 0 -> f_dc); it is called for every (k, ch),
 // with zeros for a Gaussian that is not visible, so that every output row is written.
-// moments = true (what raster_backward_kernel accumulates): r9[0..4] = (Sx, Sy, Sxx, Sxy, Syy), the moments sum du^a dv^b dL/dq
-// over the pixels; with q = A11 du^2 + 2 A12 du dv + A22 dv^2 and du = px - u:  d u = -2 (A11 Sx + A12 Sy),
-// d v = -2 (A12 Sx + A22 Sy), d A11 = Sxx, d A12 = 2 Sxy, d A22 = Syy.  moments = false: r9[0..4] are those gradients.
+// moments = true (what raster_backward_kernel accumulates): r9[0..5] = (Mx, My, Mxx, Mxy, Myy, M0), the moments sum du^a dv^b a
+// over the pixels of a = dL/d alpha * g.  dL/d opacity = M0, and dL/dq = -0.5 o a (alpha = o exp(-q/2)): with
+// q = A11 du^2 + 2 A12 du dv + A22 dv^2 and du = px - u:  d u = o (A11 Mx + A12 My), d v = o (A12 Mx + A22 My),
+// d A11 = -0.5 o Mxx, d A12 = -o Mxy, d A22 = -0.5 o Myy.  moments = false: r9[0..5] are those gradients themselves.
 template <class Coef, class Emit>
 GS_HD GradOut project_backward_core(const GaussIn& in, bool fused, Coef coef, Emit emit_sh, const Camera& cam, const ViewK& vk,
                                     bool vis, const float r9[9], bool moments = false) {
@@ -167,9 +168,11 @@ GS_HD GradOut project_backward_core(const GaussIn& in, bool fused, Coef coef, Em
         project_gaussian(in.p, S, in.o_raw, cam, vk, o, m);
         float gu = r9[0], gv = r9[1], ga = r9[2], gb = r9[3], gc = r9[4];
         if (moments) {
-            gu = -2.f * (o.A11 * r9[0] + o.A12 * r9[1]);
-            gv = -2.f * (o.A12 * r9[0] + o.A22 * r9[1]);
-            gb = 2.f * r9[3];
+            gu = o.opacity * (o.A11 * r9[0] + o.A12 * r9[1]);
+            gv = o.opacity * (o.A12 * r9[0] + o.A22 * r9[1]);
+            ga = -0.5f * o.opacity * r9[2];
+            gb = -o.opacity * r9[3];
+            gc = -0.5f * o.opacity * r9[4];
         }
         project_gaussian_backward(m, o, cam, vk, gu, gv, ga, gb, gc, r9[5], g.p, g.S9, g.o_raw);
         g.col[0] = r9[6]; g.col[1] = r9[7]; g.col[2] = r9[8];

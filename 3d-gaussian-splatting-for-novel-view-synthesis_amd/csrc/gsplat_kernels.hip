@@ -1020,6 +1020,13 @@ __device__ __forceinline__ T lds_at(const T* base, uint32_t byte_off) {
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
+// min as ONE v_min_f32 (fminf() first canonicalises a scalar operand with a v_max_f32 every time it is used; no NaNs here)
+__device__ __forceinline__ float vmin(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ int launch_priority(uint32_t b, uint32_t grid) {
     return b * 64u < grid ? 3 : (b * 16u < grid ? 2 : (b * 4u < grid ? 1 : 0));
 }
@@ -1091,8 +1098,8 @@ __global__ __launch_bounds__(64) void raster_forward_kernel(const uint2* __restr
             g0.x = __builtin_amdgcn_exp2f(q0.x); g0.y = __builtin_amdgcn_exp2f(q0.y);
             g1.x = __builtin_amdgcn_exp2f(q1.x); g1.y = __builtin_amdgcn_exp2f(q1.y);
             v2f al0 = b0.y * g0, al1 = b1.y * g1;
-            al0.x = fminf(al0.x, alpha_max); al0.y = fminf(al0.y, alpha_max);
-            al1.x = fminf(al1.x, alpha_max); al1.y = fminf(al1.y, alpha_max);
+            al0.x = vmin(al0.x, alpha_max); al0.y = vmin(al0.y, alpha_max);
+            al1.x = vmin(al1.x, alpha_max); al1.y = vmin(al1.y, alpha_max);
             // alpha = 0 outside the chi-square clip and below the cutoff (one select for both)
             al0.x = (i00 && al0.x >= alpha_cutoff) ? al0.x : 0.0f; al0.y = (i01 && al0.y >= alpha_cutoff) ? al0.y : 0.0f;
             al1.x = (i10 && al1.x >= alpha_cutoff) ? al1.x : 0.0f; al1.y = (i11 && al1.y >= alpha_cutoff) ? al1.y : 0.0f;
@@ -1138,21 +1145,24 @@ __device__ __forceinline__ float hadd(v2f a) {
 // same instructions).  Every level halves the number of live values while it sums over one more lane pairing:
 //   row_half_mirror (l <-> 7 - l), quad_perm [2,3,0,1] (l <-> l ^ 2), quad_perm [1,0,3,2] (l <-> l ^ 1):
 // a DPP add of each value with its partner lane, then a select by the lane bit: 21 instructions for 8 sums.
-#define DPP_ADD_F32(x, ctrl) ((x) + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, 0xF, 0xF, false)))
+#define DPP_MOV_F32(x, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, 0xF, 0xF, false))
+#define DPP_ADD_F32(x, ctrl) ((x) + DPP_MOV_F32(x, ctrl))
 __device__ __forceinline__ float reduce_scatter8(float (&v)[8], int lane) {
+    // per pair of values (a, b) and partner lane p: this lane keeps one of the two sums and gives the other to its partner, so
+    // keep = mine(kept) + partner's(given) -- two selects (1.3 ns each) and ONE DPP add (1.8 ns) instead of two DPP adds and a select
     const bool b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float x = DPP_ADD_F32(v[i], 0x141), y = DPP_ADD_F32(v[i + 4], 0x141);        // row_half_mirror: l <-> 7 - l
-        v[i] = b2 ? y : x;
+        const float keep = b2 ? v[i + 4] : v[i], give = b2 ? v[i] : v[i + 4];
+        v[i] = keep + DPP_MOV_F32(give, 0x141);                                             // row_half_mirror: l <-> 7 - l
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const float x = DPP_ADD_F32(v[i], 0x4E), y = DPP_ADD_F32(v[i + 2], 0x4E);          // quad_perm [2,3,0,1]
-        v[i] = b1 ? y : x;
+        const float keep = b1 ? v[i + 2] : v[i], give = b1 ? v[i] : v[i + 2];
+        v[i] = keep + DPP_MOV_F32(give, 0x4E);                                              // quad_perm [2,3,0,1]
     }
-    const float x = DPP_ADD_F32(v[0], 0xB1), y = DPP_ADD_F32(v[1], 0xB1);                  // quad_perm [1,0,3,2]
-    return b0 ? y : x;
+    const float keep = b0 ? v[1] : v[0], give = b0 ? v[0] : v[1];
+    return keep + DPP_MOV_F32(give, 0xB1);                                                  // quad_perm [1,0,3,2]
 }
 // total of x over the lane's group of 8, in every lane of the group
 __device__ __forceinline__ float all_reduce8(float x) {
@@ -1161,6 +1171,7 @@ __device__ __forceinline__ float all_reduce8(float x) {
     return DPP_ADD_F32(x, 0xB1);
 }
 #undef DPP_ADD_F32
+#undef DPP_MOV_F32
 
 constexpr int MAXQ_BWD = 32;                         // backward: longest queue per chunk (sizes the slot block below)
 
@@ -1241,7 +1252,7 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
         Gr = v2f{g[0][0], g[1][0]}; Gg = v2f{g[0][1], g[1][1]}; Gb = v2f{g[0][2], g[1][2]};
         suffix = v2f{sfx[0], sfx[1]};
     }
-    const float chik = chi * QK;
+    const float chik = chi * QK, amax = alpha_max;
     if (lane == 0) { s.r0[CHUNK] = f4{0.f, 0.f, 0.f, 0.f}; s.r1[CHUNK] = f4{0.f, 0.f, 0.f, 0.f}; s.r2[CHUNK] = f4{0.f, 0.f, 0.f, 0.f}; }
     bool alive_any = __any(va || vb);
     uint32_t base = rg.x;
@@ -1283,35 +1294,35 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
             g.x = __builtin_amdgcn_exp2f(q.x);
             g.y = __builtin_amdgcn_exp2f(q.y);
             const v2f og = go * g;
+            // alpha = min(o g, alpha_max) where q <= chi and that is >= alpha_cutoff (<=> o g >= alpha_cutoff: cutoff <= alpha_max), else 0
+            const bool p0 = i0 && og.x >= alpha_cutoff, p1 = i1 && og.y >= alpha_cutoff;
             v2f al;
-            al.x = fminf(og.x, alpha_max); al.y = fminf(og.y, alpha_max);
-            al.x = (i0 && al.x >= alpha_cutoff) ? al.x : 0.0f; al.y = (i1 && al.y >= alpha_cutoff) ? al.y : 0.0f;
-            const bool act0 = (T.x > 5e-5f) && (al.x > 0.0f), act1 = (T.y > 5e-5f) && (al.y > 0.0f);
+            al.x = p0 ? vmin(og.x, amax) : 0.0f; al.y = p1 ? vmin(og.y, amax) : 0.0f;
+            const bool alive0 = T.x > 5e-5f, alive1 = T.y > 5e-5f;
             v2f w = al * T;
-            w.x = act0 ? w.x : 0.0f; w.y = act1 ? w.y : 0.0f;
+            w.x = alive0 ? w.x : 0.0f; w.y = alive1 ? w.y : 0.0f;
             const v2f sdot = b.z * Gr + b.w * Gg + cbl * Gb;
             const v2f ar = w * Gr, ag = w * Gg, ab = w * Gb;
             suffix -= w * sdot;                                            // now the sum over k > i
             v2f om = 1.0f - al;
             om.x = __builtin_amdgcn_rcpf(om.x); om.y = __builtin_amdgcn_rcpf(om.y);   // 1 - alpha >= 0.01
             v2f dal = T * sdot - suffix * om;
-            // clamp_max passes the gradient where o g <= alpha_max (render.py:372); alpha > 0 implies q <= chi
-            dal.x = (act0 && og.x <= alpha_max) ? dal.x : 0.0f;
-            dal.y = (act1 && og.y <= alpha_max) ? dal.y : 0.0f;
+            // the pixel is alive, alpha passed its two tests, and clamp_max passes the gradient where o g <= alpha_max (render.py:372)
+            dal.x = (alive0 && p0 && og.x <= alpha_max) ? dal.x : 0.0f;
+            dal.y = (alive1 && p1 && og.y <= alpha_max) ? dal.y : 0.0f;
+            // a = dL/d alpha * g.  dL/d opacity = sum a, and dL/dq = -0.5 o a: the factor -0.5 o is the same for all pixels of a
+            // Gaussian, so the moments are taken of `a` and project_backward_kernel multiplies once per Gaussian:
+            //   d u = o (A11 Mx + A12 My), d v = o (A12 Mx + A22 My), d A11 = -0.5 o Mxx, d A12 = -o Mxy, d A22 = -0.5 o Myy
             const v2f ao = dal * g;
-            const v2f dq = (-0.5f * go) * (g * dal);                       // dL/dq (q un-scaled)
-            const v2f dvq = dv * dq;
-            const float dqs = hadd(dq), dvqs = hadd(dvq);
-            const v2f aA22 = dv * dvq;
-            // first and second moments of dL/dq over the group's pixels; project_backward_kernel turns them into
-            // the gradients of (u, v, A11, A12, A22): d u = -2 (A11 Sx + A12 Sy), d A12 = 2 Sxy, ...
+            const v2f dva = dv * ao;
+            const float m0 = hadd(ao), my = hadd(dva);
             float r[8];
-            r[0] = du * dqs;                                               // Sx  = sum du dq
-            r[1] = dvqs;                                                   // Sy  = sum dv dq
-            r[2] = du * r[0];                                              // Sxx = sum du^2 dq
-            r[3] = du * dvqs;                                              // Sxy = sum du dv dq
-            r[4] = hadd(aA22);                                             // Syy = sum dv^2 dq
-            r[5] = hadd(ao);                                               // d opacity
+            r[0] = du * m0;                                                // Mx  = sum du a
+            r[1] = my;                                                     // My  = sum dv a
+            r[2] = du * r[0];                                              // Mxx = sum du^2 a
+            r[3] = du * my;                                                // Mxy = sum du dv a
+            r[4] = hadd(dv * dva);                                         // Myy = sum dv^2 a
+            r[5] = m0;                                                     // M0  = sum a = dL/d opacity
             r[6] = hadd(ar); r[7] = hadd(ag);                              // d r, d g
             const float tot_b = all_reduce8(hadd(ab));                     // d b
             myslot[k * 9] = reduce_scatter8(r, lane);

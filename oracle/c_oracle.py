@@ -20,6 +20,9 @@ _lib = None
 
 def lib():
     global _lib
+    if _lib is None and os.environ.get("GS_ORACLE_LIB"):   # `make check-asan`: the sanitizer build
+        _lib = C.CDLL(os.environ["GS_ORACLE_LIB"])
+        _lib.ora_render.restype = C.c_int
     if _lib is None:
         src = os.path.join(HERE, "gs_oracle.c")
         if not os.path.exists(SO) or os.path.getmtime(src) > os.path.getmtime(SO):

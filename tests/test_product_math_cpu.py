@@ -22,6 +22,8 @@ CSRC = os.path.join(os.path.dirname(abi.__file__), "csrc")
 
 @pytest.fixture(scope="module")
 def hm():
+    if os.environ.get("GSPLAT_HOSTMATH_LIB"):              # `make check-asan`: the AddressSanitizer / UBSan build of the same sources
+        return C.CDLL(os.environ["GSPLAT_HOSTMATH_LIB"])
     so = os.path.join(CSRC, "libgsmath_host.so")
     srcs = [os.path.join(CSRC, f) for f in ("host_math_check.cpp", "gs_math.h", "gs_body.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
