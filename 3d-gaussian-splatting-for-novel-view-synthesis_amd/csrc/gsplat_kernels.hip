@@ -960,6 +960,7 @@ __device__ __forceinline__ Staged stage_chunk(RasterLds& s, const Candidate& c, 
                                               uint64_t& ranks) {
     __syncthreads();       // previous chunk's LDS reads are done (single-wave block: orders LDS traffic only)
     m8 = 0u;
+    if (lane == 63) { s.r0[CHUNK] = f4{0.f, 0.f, 0.f, 0.f}; s.r1[CHUNK] = f4{0.f, 0.f, 0.f, 0.f}; s.r2[CHUNK] = f4{0.f, 0.f, 0.f, 0.f}; }
     if (lane < n) {
         // conic pre-scaled by k = -0.5 log2(e): the loop evaluates q' = k q and alpha = o * exp2(q') (v_exp_f32 directly)
         s.r0[lane] = f4{c.q0.x, c.q0.y, QK * c.q0.z, (2.0f * QK) * c.q0.w};
@@ -1068,7 +1069,6 @@ __global__ __launch_bounds__(64) void raster_forward_kernel(const uint2* __restr
     v2f Cr = {0.f, 0.f}, Cg = {0.f, 0.f}, Cb = {0.f, 0.f};
     const uint2 rg = ranges[list];
     const float chik = chi * QK;
-    if (lane == 0) { s.r0[CHUNK] = f4{0.f, 0.f, 0.f, 0.f}; s.r1[CHUNK] = f4{0.f, 0.f, 0.f, 0.f}; s.r2[CHUNK] = f4{0.f, 0.f, 0.f, 0.f}; }
     bool alive_any = __any(va || vb);
     uint32_t base = rg.x;
     Candidate cand;
@@ -1173,17 +1173,27 @@ __device__ __forceinline__ float all_reduce8(float x) {
 #undef DPP_ADD_F32
 #undef DPP_MOV_F32
 
-constexpr int MAXQ_BWD = 32;                         // backward: longest queue per chunk (sizes the slot block below)
+#ifndef GSPLAT_MAXQ_BWD
+#define GSPLAT_MAXQ_BWD 28
+#endif
+#ifndef GSPLAT_BWD_WAVES
+#define GSPLAT_BWD_WAVES 1
+#endif
+constexpr int MAXQ_BWD = GSPLAT_MAXQ_BWD;            // backward: longest queue per chunk (sizes the slot block below)
 
 // LDS of the backward kernel.  LDS float atomics are slow on this hardware (a ds_add_f32 wave-instruction with 64 lanes cost
 // ~100 LDS cycles here: 230 us of a 450 us kernel), so nothing is accumulated with them: every group writes the nine sums of
 // iteration k to its own slot (plain stores), and after the chunk each entry's lane adds up the slots of the sub-tiles it
 // was queued in (it knows its rank in every queue) and leaves the row in `acc` for the flush.
+// LDS per wave decides the occupancy here (12.8 KB -> 12 waves per CU): the chunk's rows `acc` [entry][9] reuse the record
+// arrays, which are dead once the chunk's loop is over (the null record is rewritten by every stage_chunk).
 struct RasterLdsBwd {
     RasterLds f;
     float slots[N_SUB * MAXQ_BWD * 9];   // [sub-tile][queue position][9 sums]
-    float acc[CHUNK * 9];                // [entry][9 sums] of the chunk
+    uint32_t eid[CHUNK];                 // Gaussian id of every entry of the chunk
+    uint32_t eslot[CHUNK];               // (deterministic mode) the row's slot
 };
+static_assert(sizeof(f4) * 3 * (CHUNK + 1) >= sizeof(float) * CHUNK * 9, "acc must fit into the record arrays");
 
 // K7: same traversal as K6 (identical T_i and alive decisions).  For pixel p and Gaussian i:
 //   d alpha_i = alive_i T_i (c_i . Gc) - (sum_{k>i} w_k (c_k . Gc)) / (1 - alpha_i),
@@ -1203,7 +1213,7 @@ struct DetArgs {
 };
 
 template <bool DET>
-__global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ ids,
+__global__ __launch_bounds__(64, GSPLAT_BWD_WAVES) void raster_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ ids,
                                                              const Rec64* __restrict__ rec, const uint32_t* __restrict__ order,
                                                              int lists_x, int H, int W, float chi, float alpha_max,
                                                              float alpha_cutoff, const float* __restrict__ accum,
@@ -1253,7 +1263,6 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
         suffix = v2f{sfx[0], sfx[1]};
     }
     const float chik = chi * QK, amax = alpha_max;
-    if (lane == 0) { s.r0[CHUNK] = f4{0.f, 0.f, 0.f, 0.f}; s.r1[CHUNK] = f4{0.f, 0.f, 0.f, 0.f}; s.r2[CHUNK] = f4{0.f, 0.f, 0.f, 0.f}; }
     bool alive_any = __any(va || vb);
     uint32_t base = rg.x;
     Candidate cand;
@@ -1261,11 +1270,13 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
     const int my_g = lane / 9, my_k = lane - 9 * my_g;             // flush: lane i carries sum my_k of the round's row my_g
     const uint16_t* myq = &s.q[grp][0];
     float* const myslot = &sb.slots[grp * MAXQ_BWD * 9 + j];       // + 9 k: where lane j of the group puts sum j of iteration k
+    float* const acc = reinterpret_cast<float*>(&sb.f);            // [entry][9]: over the record arrays, between a chunk's loop and the next stage
     while (alive_any && base < rg.y) {
         uint32_t m8;
         uint64_t ranks;
         const Staged sg = stage_chunk<MAXQ_BWD>(s, cand, (int)min(rg.y - base, (uint32_t)CHUNK), lane, ox, oy, m8, ranks);
         const int n = sg.n, maxc = sg.maxc;
+        sb.eid[lane] = cand.id;
         base += (uint32_t)n;
         if (base < rg.y) cand = fetch_candidate(lane, base, rg.y, ids, rec, id_max);   // in flight during the loop below
         ++st_chunks;
@@ -1349,28 +1360,28 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
                 }
             }
 #pragma unroll
-            for (int v = 0; v < 9; ++v) sb.acc[lane * 9 + v] = tot[v];
+            for (int v = 0; v < 9; ++v) acc[lane * 9 + v] = tot[v];
         }
         if (DET && lane < n) {       // entry `lane`: its row's slot = first slot of its Gaussian + ordinal of this list in its rectangle
-            const uint32_t id = __float_as_uint(s.r2[lane].y);
+            const uint32_t id = sb.eid[lane];
             const u2 rc = det.rect[id];
             const uint32_t mk = det.mask[id], nt = det.tiles[id];
             const int x0 = (int)(rc.x & 0xFFFFu), y0 = (int)(rc.x >> 16), x1 = (int)(rc.y & 0xFFFFu);
             const uint32_t bit = (uint32_t)((hy - y0) * (x1 - x0 + 1) + (tx - x0));          // row-major, like for_each_list
             const uint32_t ord = nt > 32u ? bit : (uint32_t)__popc(mk & ((1u << (bit & 31u)) - 1u));
-            s.r2[lane].z = __uint_as_float(det.pair_base[id] + ord);
+            sb.eslot[lane] = det.pair_base[id] + ord;
         }
         __syncthreads();
         // the chunk's rows -> grad2d: 7 rows x 9 sums per atomic instruction, one 36-byte request per row
         for (int t0 = 0; t0 < n; t0 += 7) {
             const int c = t0 + my_g;
             if (lane < 63 && c < n) {
-                const float val = sb.acc[c * 9 + my_k];
+                const float val = acc[c * 9 + my_k];
                 if (DET) {
-                    const uint32_t slot = __float_as_uint(s.r2[c].z);
+                    const uint32_t slot = sb.eslot[c];
                     if (slot < det.capacity) det.part[(int64_t)slot * 9 + my_k] = val;
                 } else if (val != 0.0f) {
-                    atomicAdd(&grad2d[(int64_t)__float_as_uint(s.r2[c].y) * 16 + my_k], val);
+                    atomicAdd(&grad2d[(int64_t)sb.eid[c] * 16 + my_k], val);
                 }
             }
         }

@@ -192,6 +192,24 @@ class DeferredChecks:
     def __init__(self):
         self.pending = []          # (pinned counter block, event, capacity, device)
         self.counts = []
+        self._overflow = self._offscreen = False
+
+    def add(self, pinned, event, capacity, device):
+        self.pending.append((pinned, event, capacity, device))
+        if len(self.pending) >= PINNED_SLOTS // 2:           # long sequences: look at the oldest frames before their pinned
+            self._drain(len(self.pending) // 2)              # counter blocks come round again (they finished long ago)
+
+    def _drain(self, count):
+        global _last_counts
+        for pinned, ev, cap, dev in self.pending[:count]:
+            ev.synchronize()
+            counts = _abi.Counts.from_buffer_copy(pinned.numpy().tobytes())
+            self.counts.append(counts)
+            _ws.note_pairs(dev, counts.n_binned)
+            self._overflow |= cap is not None and counts.n_binned > cap
+            self._offscreen |= _abi.lib().gsplat_classify_counts(C.byref(counts)) == _abi.GSPLAT_SCENE_ALL_OFFSCREEN
+            _last_counts = (counts.n_survivors, counts.n_visible, int(counts.n_pairs))
+        del self.pending[:count]
 
     def __enter__(self):
         _deferred_stack.append(self)
@@ -202,17 +220,9 @@ class DeferredChecks:
         return False
 
     def verify(self):
-        global _last_counts
-        pending, self.pending = self.pending, []
-        overflow, offscreen = False, False
-        for pinned, ev, cap, dev in pending:
-            ev.synchronize()
-            counts = _abi.Counts.from_buffer_copy(pinned.numpy().tobytes())
-            self.counts.append(counts)
-            _ws.note_pairs(dev, counts.n_binned)
-            overflow |= cap is not None and counts.n_binned > cap
-            offscreen |= _abi.lib().gsplat_classify_counts(C.byref(counts)) == _abi.GSPLAT_SCENE_ALL_OFFSCREEN
-            _last_counts = (counts.n_survivors, counts.n_visible, int(counts.n_pairs))
+        self._drain(len(self.pending))
+        overflow, offscreen = self._overflow, self._offscreen
+        self._overflow = self._offscreen = False
         if offscreen:
             raise Exception(OFFSCREEN_MSG)
         if overflow:
@@ -303,7 +313,7 @@ def _forward_end(pend, need_grad):
             counts = None
             fr.n_pairs = int(pend.capacity)
             forward_modes["deferred"] += 1
-            _deferred_stack[-1].pending.append((pend.pinned, pend.ready, fr.n_pairs, dev))
+            _deferred_stack[-1].add(pend.pinned, pend.ready, fr.n_pairs, dev)
         else:
             pend.ready.synchronize()
             forward_modes["waited"] += 1
@@ -506,12 +516,29 @@ def render_frames(pos, f_dc, f_rest, opacity_raw, scale_raw, q_raw, c2ws, H, W, 
     """Forward-only rendering of a sequence of camera poses with the frames software-pipelined over two HIP streams:
     frame k + 1's projection / binning front (latency- and bandwidth-bound) overlaps frame k's rasterisation (VALU-bound).
     Same images as render_gaussians() frame by frame.  Returns the list of images (or calls on_frame(k, image) and returns
-    None); the caller's current stream waits for all of them."""
+    None); the caller's current stream waits for all of them.  Without on_frame, and once a pair capacity is known for the
+    device, no frame waits for its counters either (deferred_checks: the per-frame checks are made after the last frame is
+    queued; a sequence that outgrows the buffers is rendered again)."""
     view = _view(H, W, fx, fy, cx, cy, near, far, pix_guard, T, min_conis, chi_square_clip, alpha_max, alpha_cutoff)
     dev = pos.device
+    cams = [torch.as_tensor(c, dtype=torch.float32, device=dev) if not isinstance(c, torch.Tensor) else c for c in c2ws]
+    args = (view, dev, cams, pos, f_dc, f_rest, opacity_raw, scale_raw, q_raw)
+    if on_frame is not None or _ws.pair_capacity(dev) == 0 or _deferred_stack:
+        return _render_frames(*args, on_frame)
+    for _ in range(4):
+        with deferred_checks() as chk:
+            images = _render_frames(*args, None)
+        try:
+            chk.verify()
+            return images
+        except PairCapacityExceeded:
+            continue
+    raise RuntimeError("the pair buffers overflowed four times in a row")
+
+
+def _render_frames(view, dev, cams, pos, f_dc, f_rest, opacity_raw, scale_raw, q_raw, on_frame):
     main = torch.cuda.current_stream(dev)
     streams = _pipeline_streams(dev)
-    cams = [torch.as_tensor(c, dtype=torch.float32, device=dev) if not isinstance(c, torch.Tensor) else c for c in c2ws]
     for st in streams:
         st.wait_stream(main)                                   # parameters and camera matrices produced on the caller's stream
 

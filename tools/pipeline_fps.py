@@ -23,7 +23,8 @@ with torch.no_grad():
     torch.cuda.synchronize()
     print("max |pipelined - sequential| over 8 frames:", max(float((a - b).abs().max()) for a, b in zip(ref, got)))
     for name, fn in (("sequential", lambda: [gs.render_gaussians(*p, c, *cargs) for c in cams]),
-                     ("pipelined", lambda: gs.render_frames(*p, cams, *cargs, on_frame=lambda k, im: None))):
+                     ("pipelined, waiting per frame (on_frame)", lambda: gs.render_frames(*p, cams, *cargs, on_frame=lambda k, im: None)),
+                     ("pipelined, no waiting (deferred checks)", lambda: gs.render_frames(*p, cams, *cargs))):
         fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()

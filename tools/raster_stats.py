@@ -1,8 +1,15 @@
 #!/usr/bin/env python3
-"""Per-wave statistics of the raster kernels on the benchmark scene (diagnostic; needs a GPU)."""
+"""Per-wave statistics of the raster kernels on the benchmark scene (diagnostic; needs a GPU).  Uses the DIAGNOSTICS build of the
+library (the product library has no statistics hook):
+    make -C 3d-gaussian-splatting-for-novel-view-synthesis_amd/csrc libgsplat_mi355x_diag.so
+    python tools/raster_stats.py [config]"""
 import ctypes as C
 import importlib
+import os
 import sys
+
+os.environ.setdefault("GSPLAT_MI355X_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                        "3d-gaussian-splatting-for-novel-view-synthesis_amd", "csrc", "libgsplat_mi355x_diag.so"))
 
 import numpy as np
 import torch
@@ -37,8 +44,9 @@ for name, t in (("forward", sf), ("backward", sb)):
     a = t.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
     ln, ch, vis, cyc = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
     act = ln > 0
-    print(f"{name}: regions {act.sum()}  list_len mean {ln[act].mean():.0f} max {ln.max()}  chunks mean {ch[act].mean():.1f} max {ch.max()} "
-          f" visited mean {vis[act].mean():.0f} max {vis.max()} total {vis.sum() / 1e6:.2f}M")
+    # "visited" = loop iterations (longest sub-tile queue of every chunk, summed): 8 (sub-tile, Gaussian) pairs each when balanced
+    print(f"{name}: lists {act.sum()}  list_len mean {ln[act].mean():.0f} max {ln.max()}  chunks mean {ch[act].mean():.1f} max {ch.max()} "
+          f" iterations mean {vis[act].mean():.0f} max {vis.max()} total {vis.sum() / 1e6:.2f}M  (entries / iteration {ln.sum() / max(vis.sum(), 1):.2f})")
     print(f"   cycles: mean {cyc[act].mean():.0f} p50 {np.percentile(cyc[act], 50):.0f} p90 {np.percentile(cyc[act], 90):.0f} "
           f"p99 {np.percentile(cyc[act], 99):.0f} max {cyc.max()}  (100 MHz ticks? see below)  sum {cyc.sum() / 1e6:.1f}M")
     i = np.argsort(cyc)[-5:][::-1]
