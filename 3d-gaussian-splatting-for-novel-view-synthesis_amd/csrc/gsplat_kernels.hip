@@ -1173,13 +1173,9 @@ __device__ __forceinline__ float all_reduce8(float x) {
 #undef DPP_ADD_F32
 #undef DPP_MOV_F32
 
-#ifndef GSPLAT_MAXQ_BWD
-#define GSPLAT_MAXQ_BWD 28
-#endif
-#ifndef GSPLAT_BWD_WAVES
-#define GSPLAT_BWD_WAVES 1
-#endif
-constexpr int MAXQ_BWD = GSPLAT_MAXQ_BWD;            // backward: longest queue per chunk (sizes the slot block below)
+// backward: longest queue per chunk (sizes the slot block below).  Measured at 16 / 20 / 24 / 28 / 32: 253 / 249-258 / 247 / 249 / 269 us
+// (config 3): below 12.8 KB of LDS per wave the occupancy gain is eaten by chunks cut short.
+constexpr int MAXQ_BWD = 28;
 
 // LDS of the backward kernel.  LDS float atomics are slow on this hardware (a ds_add_f32 wave-instruction with 64 lanes cost
 // ~100 LDS cycles here: 230 us of a 450 us kernel), so nothing is accumulated with them: every group writes the nine sums of
@@ -1213,7 +1209,7 @@ struct DetArgs {
 };
 
 template <bool DET>
-__global__ __launch_bounds__(64, GSPLAT_BWD_WAVES) void raster_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ ids,
+__global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ ids,
                                                              const Rec64* __restrict__ rec, const uint32_t* __restrict__ order,
                                                              int lists_x, int H, int W, float chi, float alpha_max,
                                                              float alpha_cutoff, const float* __restrict__ accum,
@@ -1344,9 +1340,6 @@ __global__ __launch_bounds__(64, GSPLAT_BWD_WAVES) void raster_backward_kernel(c
           if (!__any(T.x > 5e-5f || T.y > 5e-5f)) break;          // every 8 entries: all pixels dead
         }
         alive_any = __any(T.x > 5e-5f || T.y > 5e-5f);        // dead pixels stay dead
-#ifdef GSPLAT_EXP_NO_GATHER
-        continue;
-#endif
         __syncthreads();
         {   // entry `lane`: add up the slots of the sub-tiles it was queued in
             float tot[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
