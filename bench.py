@@ -96,9 +96,10 @@ KERNEL_OF_STAGE = {"project": "project_kernel+bin_count_kernel+colour_kernel", "
                    "project_backward": "project_backward_kernel"}
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch from a committed PMC profile (profiles/pmc_traffic.json), if present for this kernel."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+def pmc_traffic(kernel, config=3):
+    """HBM bytes per launch from a committed PMC profile of THIS scene (profiles/pmc_traffic_config<N>.json: separate rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE passes, tools/profile_all.sh), if present for this kernel; else null."""
+    path = os.path.join(ROOT, "profiles", f"pmc_traffic_config{config}.json")
     try:
         with open(path) as f:
             d = json.load(f)
@@ -440,7 +441,7 @@ def main():
                                  "not waited for: buffers from earlier frames, checks once per step (ops.deferred_checks, as Trainer.step)"},
             "fps": world * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(KERNEL_OF_STAGE[dom]), "kernel": KERNEL_OF_STAGE[dom],
+                         "traffic": pmc_traffic(KERNEL_OF_STAGE[dom], args.config), "kernel": KERNEL_OF_STAGE[dom],
                          "avg_launch_ms": per_stage[dom]["avg_ms"], "alg_bytes_per_launch": per_stage[dom]["alg_bytes"],
                          "note": "the raster kernels are VALU-bound, not HBM-bound (DESIGN.md section 6): the HBM fraction of this "
                                  "kernel is small by construction; pipeline_roofline prices the whole step"},
@@ -533,7 +534,8 @@ def single_gpu_extras(gs, ops, params, cam, cam_args, dev, fence):
         out["config5"] = {"workload": "config 5: 10 M Gaussians, 3840x2160, SH 3, forward + backward", "ms_per_step": ms5,
                           "mpix_per_s": HW5 / (ms5 * 1e-3) / 1e6, "V": V5, "P": P5, "stage_ms": st,
                           "dominant": {"kernel": KERNEL_OF_STAGE[dom5], "avg_ms": st[dom5],
-                                       "frac": algorithmic_bytes(dom5, N5, V5, P5, HW5) / (st[dom5] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                                       "frac": algorithmic_bytes(dom5, N5, V5, P5, HW5) / (st[dom5] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                       "traffic": pmc_traffic(KERNEL_OF_STAGE[dom5], 5)},
                           "pipeline_frac": alg5 / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBS}
     except Exception as e:                        # never take the headline line down
         out["config5"] = {"error": f"{type(e).__name__}: {e}"}

@@ -141,3 +141,25 @@ def exact_vs_bbox(config=3, sample=100_000, sw=4, sh=4):
 if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "exact":
     exact_vs_bbox(int(sys.argv[1]), 30_000, 4, 4)
     exact_vs_bbox(int(sys.argv[1]), 30_000, 4, 2)
+
+
+def disc_vs_bbox(config=3, sample=20000, sw=4, sh=4):
+    """Cheap conservative refinement of the bounding-box test: {q <= chi} lies inside the disc of radius sqrt(chi / lambda_min(conic))
+    around the centre, so a sub-tile whose nearest point is farther than that cannot be touched."""
+    pos, scale, q, op, H, W, fx = scene(config)
+    u, v, ex, ey, A11, A12, A22, o = project(pos, scale, q, op, H, W, fx)
+    idx = np.random.default_rng(1).choice(len(u), size=min(sample, len(u)), replace=False)
+    u, v, ex, ey, A11, A12, A22 = (a[idx] for a in (u, v, ex, ey, A11, A12, A22))
+    lam = 0.5 * (A11 + A22) - np.sqrt(0.25 * (A11 - A22) ** 2 + A12 ** 2)
+    r2 = 6.25 / lam * 1.002 + 0.05
+    x0 = np.clip(np.ceil(u - ex), 0, W - 1); x1 = np.clip(np.floor(u + ex), 0, W - 1)
+    y0 = np.clip(np.ceil(v - ey), 0, H - 1); y1 = np.clip(np.floor(v + ey), 0, H - 1)
+    bb = dd = 0
+    for i in range(len(u)):
+        for ty in range(int(y0[i]) // sh, int(y1[i]) // sh + 1):
+            for tx in range(int(x0[i]) // sw, int(x1[i]) // sw + 1):
+                bb += 1
+                dx = max(tx * sw - u[i], 0.0, u[i] - (tx * sw + sw - 1))
+                dy = max(ty * sh - v[i], 0.0, v[i] - (ty * sh + sh - 1))
+                dd += dx * dx + dy * dy <= r2[i]
+    print(f"  sub-tiles {sw}x{sh}: bounding-box pairs {bb}, box + disc pairs {dd}: {dd / bb:.3f}")
