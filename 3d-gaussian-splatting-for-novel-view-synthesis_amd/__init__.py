@@ -11,7 +11,7 @@ or through the alias module `gsplat_amd` at the repository root.  Same eight nam
 plus the fused entry `render_gaussians` and the data-parallel helpers in `.dp`.
 """
 from .ops import (HARMONICS, build_sigma_from_params, evaluate_sh, inv2x2, project_points, quat_to_rotmat, render,
-                  render_frames, render_gaussians, render_stats, scale_intrinsics, deferred_checks, set_deterministic,
+                  render_frames, render_gaussians, render_stats, scale_intrinsics, deferred_checks, run_deferred, set_deterministic,
                   PairCapacityExceeded)
 
 from . import losses  # noqa: E402,F401  (L1 + SSIM loss, SURVEY §8f next row 1)
@@ -25,6 +25,6 @@ from . import training  # noqa: E402,F401  (one training iteration of the refere
 
 __all__ = [
     'build_sigma_from_params', 'quat_to_rotmat', 'evaluate_sh', 'HARMONICS', 'render', 'project_points', 'inv2x2',
-    'scale_intrinsics', 'render_gaussians', 'render_stats', 'render_frames', 'deferred_checks', 'set_deterministic',
+    'scale_intrinsics', 'render_gaussians', 'render_stats', 'render_frames', 'deferred_checks', 'run_deferred', 'set_deterministic',
     'PairCapacityExceeded',
 ]

@@ -238,6 +238,21 @@ def deferred_checks():
     return DeferredChecks()
 
 
+def run_deferred(fn, attempts=4):
+    """fn() queues renders (and their backward passes) -- it runs inside deferred_checks() and is REPEATED while one of its frames
+    outgrows the pair buffers kept from earlier frames (the capacity is raised each time; the first frame of a much larger scene
+    does that once).  Returns fn()'s result of the pass that passed its checks; the off-screen exception propagates."""
+    for _ in range(attempts):
+        with deferred_checks() as chk:
+            out = fn()
+        try:
+            chk.verify()
+            return out
+        except PairCapacityExceeded:
+            continue
+    raise RuntimeError(f"the pair buffers overflowed {attempts} times in a row")
+
+
 def _make_gaussians(n, pos, opacity_raw, color=None, sigma=None, scale_raw=None, q_raw=None, f_dc=None, f_rest=None):
     return _abi.Gaussians(n, _p(pos), _p(opacity_raw), _p(color), _p(sigma), _p(scale_raw), _p(q_raw), _p(f_dc), _p(f_rest))
 
@@ -525,15 +540,7 @@ def render_frames(pos, f_dc, f_rest, opacity_raw, scale_raw, q_raw, c2ws, H, W, 
     args = (view, dev, cams, pos, f_dc, f_rest, opacity_raw, scale_raw, q_raw)
     if on_frame is not None or _ws.pair_capacity(dev) == 0 or _deferred_stack:
         return _render_frames(*args, on_frame)
-    for _ in range(4):
-        with deferred_checks() as chk:
-            images = _render_frames(*args, None)
-        try:
-            chk.verify()
-            return images
-        except PairCapacityExceeded:
-            continue
-    raise RuntimeError("the pair buffers overflowed four times in a row")
+    return run_deferred(lambda: _render_frames(*args, None))
 
 
 def _render_frames(view, dev, cams, pos, f_dc, f_rest, opacity_raw, scale_raw, q_raw, on_frame):

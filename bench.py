@@ -293,44 +293,44 @@ def main():
 
     info = {"allreduce": None}
 
-    import contextlib
-
-    def checks():
+    def checked(fn):
         # the way training.Trainer.step renders: no wait for the frame's pair count (buffers sized from earlier frames, SH colour
-        # inside the projection kernel); the frame's checks (off-screen exception, buffer capacity) are made by verify() below,
-        # inside the step.  --wait-counts: the reference-style call that waits for the counters in the middle of the forward pass.
-        return contextlib.nullcontext() if args.wait_counts else ops.deferred_checks()
+        # inside the projection kernel); the frame's checks (off-screen exception, buffer capacity) are made inside the step, once
+        # (ops.run_deferred: the pass is repeated if a frame outgrew the buffers).  --wait-counts: the reference-style call that
+        # waits for the counters in the middle of the forward pass.
+        return fn() if args.wait_counts else ops.run_deferred(fn)
+
+    def render_pass():
+        if need_grad:
+            for p in params.values():
+                p.grad = None
+            gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args).backward(gimg)
+        else:
+            with torch.no_grad():
+                gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args)
 
     def local_step():
-        with checks() as chk:
-            if need_grad:
-                for p in params.values():
-                    p.grad = None
-                gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args).backward(gimg)
-            else:
-                with torch.no_grad():
-                    gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args)
-        if chk is not None:
-            chk.verify()
+        checked(render_pass)
 
     def step():
         if not need_grad or world == 1:
             return local_step()
-        for p in params.values():
-            p.grad = None
-        with checks() as chk:
-            if args.exchange == "factored":
+        if args.exchange == "factored":
+            def factored_pass():
+                for p in params.values():
+                    p.grad = None
                 with dp.FactoredExchange(params, world_views=world) as ex:
                     gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args).backward(gimg)
-            else:
-                gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args).backward(gimg)
-        if chk is not None:
-            chk.verify()
-        if args.exchange == "factored":
+                return ex
+            # (a repeat would re-issue this rank's collectives: it cannot happen in the timed region -- every rank renders the same view
+            # in every step, and the warm-up steps left it the capacity of that view; training.Trainer.step, where views change, agrees
+            # on a repeat across the ranks)
+            ex = checked(factored_pass)
             ex.finish()
             info["allreduce"] = "factored: all-reduce of pos/opacity/scale/rotation gradients (44 B per Gaussian) + all-gather " \
                                 "of colour-logit gradients (12 B per Gaussian and view) + local SH rebuild"
         else:
+            checked(render_pass)
             grads = [params[k].grad for k in NAMES]
             info["allreduce"] = "one flat buffer, single collective" if dp._common_base(grads) is not None else "2 buckets"
             dp.allreduce_gradients(grads, world_views=world)
@@ -511,12 +511,13 @@ def single_gpu_extras(gs, ops, params, cam, cam_args, dev, fence):
         eye = torch.eye(4, device=dev)
         a5 = (H5, W5, cam5["fx"], cam5["fy"], cam5["cx"], cam5["cy"])
 
-        def step5():
+        def pass5():
             for p in p5.values():
                 p.grad = None
-            with ops.deferred_checks() as chk:
-                gs.render_gaussians(*[p5[k] for k in NAMES], eye, *a5).backward(g5)
-            chk.verify()
+            gs.render_gaussians(*[p5[k] for k in NAMES], eye, *a5).backward(g5)
+
+        def step5():
+            ops.run_deferred(pass5)
         for _ in range(2):
             step5()
         _, V5, P5 = gs.render_stats()
