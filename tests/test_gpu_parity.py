@@ -527,3 +527,33 @@ def test_deterministic_backward_matches_the_goldens_and_repeats_bitwise(gs, name
     for k in util.PARAMS:
         assert torch.equal(p1[k].grad, p2[k].grad), k
         util.check_grad(p1[k].grad.cpu().numpy(), d["grad_" + k], k, cal=d["grad32_" + k])
+
+
+def test_counters_arrive_by_copy_or_by_mapped_store(gs):
+    """gsplat_project hands the counters to the host either with a copy operation (any host memory, flags = 0: what the
+    INTEGRATION.md stub does) or by storing them itself into device-mapped pinned memory (GSPLAT_PROJECT_COUNTS_MAPPED); with
+    or without the SH colour inside the projection kernel the counters are the same, and the counter block is left zeroed."""
+    import ctypes as C
+    import importlib
+    abi = importlib.import_module("3d-gaussian-splatting-for-novel-view-synthesis_amd._abi")
+    lib = abi.lib()
+    d = util.load("g1_generic")
+    p = util.tensors(d, F32, device=DEV)
+    n = len(d["pos"])
+    view = abi.make_view(*util.cam_args(d))
+    g = abi.Gaussians(n, p["pos"].data_ptr(), p["opacity_raw"].data_ptr(), None, None, p["scale_raw"].data_ptr(), p["q_raw"].data_ptr(),
+                      p["f_dc"].data_ptr(), p["f_rest"].data_ptr())
+    c2w = torch.tensor(d["c2w"], device=DEV)
+    state = torch.empty(lib.gsplat_project_state_bytes(n, C.byref(view)), dtype=torch.uint8, device=DEV)
+    block = torch.zeros(lib.gsplat_project_scratch_bytes(n), dtype=torch.uint8, device=DEV)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    got = []
+    for flags in (0, abi.GSPLAT_PROJECT_COUNTS_MAPPED, abi.GSPLAT_PROJECT_COUNTS_MAPPED | abi.GSPLAT_PROJECT_COLOUR_FUSED, abi.GSPLAT_PROJECT_COLOUR_FUSED):
+        host = torch.full((C.sizeof(abi.Counts),), 255, dtype=torch.uint8).pin_memory()
+        abi.check(lib.gsplat_project(C.byref(g), C.c_void_p(c2w.data_ptr()), C.byref(view), C.c_void_p(state.data_ptr()),
+                                     C.c_void_p(block.data_ptr()), block.numel(), C.c_void_p(host.data_ptr()), None, flags, st), "gsplat_project")
+        torch.cuda.synchronize()
+        c = abi.Counts.from_buffer_copy(host.numpy().tobytes())
+        got.append((c.n_survivors, c.n_visible, c.n_pairs, c.n_binned, c.max_tiles_per_gaussian))
+        assert int(block.max()) == 0, "the counter block must be left zeroed"
+    assert len(set(got)) == 1 and got[0][1] == len(d["im_ids"]) and got[0][2] == len(d["im_pair_gauss"]), got
