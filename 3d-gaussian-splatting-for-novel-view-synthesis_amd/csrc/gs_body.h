@@ -127,9 +127,7 @@ GS_HD RecOut project_finish(const GaussIn& in, const Proj& o, bool fused, Coef c
         if (o.bx1 >= o.bx0 && o.by1 >= o.by0) {
             const uint32_t area = (uint32_t)((o.bx1 - o.bx0 + 1) * (o.by1 - o.by0 + 1));
             r.mask = o.bmask;
-            uint32_t bits = 0u;
-            for (uint32_t m = r.mask; m; m &= m - 1u) ++bits;
-            r.tiles = area > 32u ? area : bits;
+            r.tiles = area > 32u ? area : (uint32_t)__builtin_popcount(r.mask);
         }
         r.r0 = f4{o.u, o.v, o.A11, o.A12};
         r.r1 = f4{o.A22, o.opacity, o.ex, o.ey};

@@ -22,7 +22,8 @@ Extra objects on the line:
   sustained     >= 1 s of back-to-back steps after the timed region: ms/step mean, min and max over 10 windows.
   N = 1 extras  (outside the timed region; --no-extras skips them) forward_only (the reference's FPS protocol,
                 scripts/render_trained.py:319-381: frame by frame, and software-pipelined render_frames), train_step
-                (render + L1/SSIM loss + backward + clip + Adam, scripts/train.py:446-569), config5 (10 M Gaussians, 4K).
+                (render + L1/SSIM loss + backward + clip + Adam, scripts/train.py:446-569), config4 (3 M Gaussians, a training iteration
+                over 8 views on this one GPU), config5 (10 M Gaussians, 4K).
   N > 1         exchange: compute_ms (the same step without the exchange), exchange_ms (step - compute = exposed exchange
                 time), exchange_alone_ms (the collectives by themselves), bytes all-reduced / all-gathered per step, nranks.
 """
@@ -225,8 +226,8 @@ def timed(fn, steps, fence):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", type=int, default=3, help="synthetic scene of SURVEY.md §8d (default 3: 1M @ 1080p)")
     ap.add_argument("--forward-only", action="store_true", help="time forward-only inference instead of fwd+bwd")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -499,6 +500,30 @@ def single_gpu_extras(gs, ops, params, cam, cam_args, dev, fence):
     out["train_step"] = {"workload": "config 3, Trainer.step: fused render + fused L1/SSIM loss + backward + clip + fused Adam, one view",
                          "ms": timed(train_step, 20, fence)}
     del trainer, model
+    # -- config 4 of BASELINE.json on ONE GPU: the 3 M-Gaussian scene, a training iteration over 8 orbit views (what 8 ranks with one
+    #    view each do between two exchanges, here one after the other)
+    try:
+        p4_cpu, cam4 = synthetic_scene(4)
+        model4 = model_mod.GaussianModel({k: p4_cpu[k] for k in NAMES}, device=dev)
+        del p4_cpu
+        tr4 = training.Trainer(model4, training.TrainConfig())
+        g4 = torch.Generator().manual_seed(3)
+        views4 = [{"image": torch.rand(cam4["H"], cam4["W"], 3, generator=g4).to(dev), "c2w": orbit_c2w(k).to(dev), "H": cam4["H"],
+                   "W": cam4["W"], "fx": cam4["fx"], "fy": cam4["fy"], "cx": cam4["cx"], "cy": cam4["cy"]} for k in range(8)]
+        it4 = [1]
+
+        def train4():
+            tr4.step(it4[0], views4)
+            it4[0] += 1
+        for _ in range(2):
+            train4()
+        ms4 = timed(train4, 5, fence)
+        out["config4"] = {"workload": "config 4: 3 M Gaussians, 1920x1080, Trainer.step over 8 orbit views on one GPU (render + loss + backward per "
+                                      "view, then clip + Adam)", "ms_per_iteration": ms4, "ms_per_view": ms4 / 8,
+                          "mpix_per_s": 8 * cam4["H"] * cam4["W"] / (ms4 * 1e-3) / 1e6}
+        del tr4, model4, views4
+    except Exception as e:
+        out["config4"] = {"error": f"{type(e).__name__}: {e}"}
     # -- config 5 (10 M Gaussians, 3840 x 2160, forward + backward)
     for p in params.values():
         p.grad = None
