@@ -557,3 +557,28 @@ def test_counters_arrive_by_copy_or_by_mapped_store(gs):
         got.append((c.n_survivors, c.n_visible, c.n_pairs, c.n_binned, c.max_tiles_per_gaussian))
         assert int(block.max()) == 0, "the counter block must be left zeroed"
     assert len(set(got)) == 1 and got[0][1] == len(d["im_ids"]) and got[0][2] == len(d["im_pair_gauss"]), got
+
+
+def test_deterministic_backward_with_too_small_buffers_is_memory_safe(gs):
+    """Deterministic mode + a deferred frame that outgrows its buffers: rows whose slot lies beyond the capacity are dropped, not
+    written out of bounds; verify() reports the overflow and the repeat is right (and bitwise repeatable)."""
+    ops = _ops()
+    d = util.load("g1_generic")
+    _fused(gs, d, grad=False)
+    key = ("cuda", 0)
+    real = ops._ws.capacity[key]
+    old = gs.set_deterministic(True)
+    try:
+        ops._ws.capacity[key] = 200
+        with ops.deferred_checks() as chk:
+            _fused(gs, d)
+        torch.cuda.synchronize()
+        with pytest.raises(ops.PairCapacityExceeded):
+            chk.verify()
+        (_, p1), (_, p2) = gs.run_deferred(lambda: (_fused(gs, d), _fused(gs, d)))
+        for k in util.PARAMS:
+            assert torch.equal(p1[k].grad, p2[k].grad), k
+            util.check_grad(p1[k].grad.cpu().numpy(), d["grad_" + k], k, cal=d["grad32_" + k])
+    finally:
+        gs.set_deterministic(old)
+        ops._ws.capacity[key] = max(real, ops._ws.capacity[key])

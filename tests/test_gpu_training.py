@@ -273,3 +273,32 @@ def test_config4_training_iteration():
         assert moved > 0.0, f"{k} did not move"
     out2 = tr.step(2, views)           # steady state: no waiting forward, still finite
     assert np.isfinite(float(out2["loss"]))
+
+
+def test_trainer_repeats_a_pass_that_outgrew_the_pair_buffers():
+    """The pair capacity kept from earlier frames is too small for this iteration's views (as after a densification or a new
+    camera): the pass is repeated with larger buffers and the iteration's result is the one of an undisturbed iteration."""
+    model_mod = importlib.import_module(PKG + ".model")
+    training = importlib.import_module(PKG + ".training")
+    ops = importlib.import_module(PKG + ".ops")
+    s, views = _scene()
+
+    def run(shrink):
+        model = model_mod.GaussianModel({k: torch.tensor(s[k]) for k in NAMES}, device="cuda:0")
+        tr = training.Trainer(model, training.TrainConfig(densify_until_iter=0, opacity_reset_interval=10 ** 9))
+        tr.step(1, views)
+        if shrink:
+            ops._ws.capacity[("cuda", 0)] = 100               # far below the ~1600 pairs of a view
+        before = dict(ops.forward_modes)
+        out = tr.step(2, views)
+        torch.cuda.synchronize()
+        if shrink:                                            # one garbage pass + one good pass, nothing waited for
+            assert ops.forward_modes["deferred"] == before["deferred"] + 4 and ops.forward_modes["waited"] == before["waited"]
+            assert ops._ws.capacity[("cuda", 0)] > 1600
+        return float(out["loss"]), {k: getattr(model, k).detach().clone() for k in NAMES}
+
+    loss_a, pa = run(False)
+    loss_b, pb = run(True)
+    assert abs(loss_a - loss_b) <= 1e-6 * abs(loss_a)
+    for k in NAMES:      # same update up to the summation order of the gradient atomics
+        assert float((pa[k] - pb[k]).abs().max()) <= 1e-5 * max(1.0, float(pa[k].abs().max())), k
