@@ -582,3 +582,28 @@ def test_deterministic_backward_with_too_small_buffers_is_memory_safe(gs):
     finally:
         gs.set_deterministic(old)
         ops._ws.capacity[key] = max(real, ops._ws.capacity[key])
+
+
+def test_the_ctypes_stub_of_integration_md_renders_the_golden(gs):
+    """INTEGRATION.md shows the binding a maintainer of the reference would write against include/gsplat_mi355x.h: run that very
+    code (only the library path is filled in) on the un-fused golden."""
+    import os
+    import re
+    import importlib
+    abi = importlib.import_module("3d-gaussian-splatting-for-novel-view-synthesis_amd._abi")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    code = next(b for b in blocks if "def render(" in b and "C.CDLL" in b)
+    code = code.replace('C.CDLL("libgsplat_mi355x.so")', f'C.CDLL({abi.LIB_PATH!r})')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    d = util.load("g11_unfused")
+    t = {k: torch.tensor(d[k], dtype=F32, device=DEV) for k in ("pos", "opacity_raw")}
+    col = torch.tensor(d["color_in"], dtype=F32, device=DEV)
+    sig = torch.tensor(d["sigma_in"], dtype=F32, device=DEV)
+    img = ns["render"](t["pos"], col, t["opacity_raw"], sig, torch.tensor(d["c2w"], device=DEV), *util.cam_args(d))
+    torch.cuda.synchronize()
+    util.check_image(img.cpu().numpy(), d["image"])
+    again = gs.render(t["pos"], col, t["opacity_raw"], sig, torch.tensor(d["c2w"], device=DEV), *util.cam_args(d))
+    assert torch.equal(img, again)
