@@ -16,7 +16,7 @@ struct u2 { uint32_t x, y; };
 // Projected record: ONE 64-byte line per Gaussian (the rasterizer gathers records by id; three separate 16-byte
 // streams cost three cache lines per gather), plus small per-Gaussian streams for the binning kernels:
 //   rec[i] = { (u, v, A11, A12), (A22, opacity, ex, ey), (r, g, b, depth z), (unused) }
-//   rect[i] = (bx0 | by0 << 16, bx1 | by1 << 16)   inclusive rectangle of half-tile lists (16 x 8 pixels each) binned
+//   rect[i] = (bx0 | by0 << 16, bx1 | by1 << 16)   inclusive rectangle of lists (16 x 8 pixels each) binned
 //   depth[i] = z                                   tiles[i] = lists touched (0 = contributes to no pixel)
 //   mask[i]: bit k = the ellipse {q <= chi} touches list k of the rectangle (row-major; all ones for rectangles > 32 lists)
 //   ref_rect[i] (host check only) = the reference's own tile rectangle (F10), T x T tiles
@@ -73,7 +73,7 @@ struct GaussIn {
 
 struct RecOut {             // what K1 stores for one Gaussian
     f4 r0, r1, r2;
-    u2 rect;                // binned half-tile lists
+    u2 rect;                // binned lists
     uint32_t tiles;         // number of lists
     uint32_t mask;          // which lists of the rectangle (see Records)
     u2 ref_rect;            // the reference's tile rectangle (F10)

@@ -1,15 +1,15 @@
 // gsplat_kernels.hip -- MI355X (gfx950, wave64) kernels and the C ABI of include/gsplat_mi355x.h.
 //
 // Pipeline (stage ids of SURVEY.md §8a in brackets):
-//   K0  camera_kernel          c2w (device) -> Camera block, zero counters                      [F5 setup]
-//   K1  project_kernel         per Gaussian: culls, EWA, eigen clamp, conic, rectangles         [F1-F8, F10, F13]
-//   K1b colour_kernel          SH colour of the binned Gaussians (fused inputs)                 [F3]
-//   K2  finish_counts_kernel   totals of the sharded counters -> gsplat_counts
+//   K1  project_kernel         per Gaussian: camera block, culls, EWA, eigen clamp, conic, rectangles; optionally the SH colour;
+//                              counters totalled by its last wave                              [F1-F8, F10, F13 (+F3)]
+//   K1b colour_kernel          SH colour of the binned Gaussians as a pass of its own (host waits for the counters)   [F3]
 //   K3  bin_count / bin_scatter / split_count / split_scatter_kernel   two-level counting sort of the pairs by list  [F11, F12]
 //   K4  list_sort_kernel       per-list depth sort in LDS (lists of 8192+: in global memory)    [F9, F12]
 //   K5  plan_kernel            longest-first launch order of the lists, sort size classes
-//   K6  raster_forward_kernel  one wave64 per 16x8 half tile = list, 2 pixels per lane          [F14, F15]
-//   K7  raster_backward_kernel same traversal, analytic gradients, 63-value reduce-scatter      [B1]
+//   K6  raster_forward_kernel  one wave64 per 16 x 8-pixel list = eight 8-lane groups, one 4 x 4 sub-tile each   [F14, F15]
+//   K7  raster_backward_kernel same traversal, analytic gradients, sums per group -> LDS slots -> one atomic per pair   [B1]
+//       (+ tile_block_sum / pair_base / pair_reduce_kernel: deterministic mode)
 //   K8  project_backward_kernel chain rule to the reference's input tensors                     [B2, B3]
 //
 // Everything is hand-written HIP for gfx950; no library kernels.  No MFMA: there is no dense contraction on this path.
@@ -55,7 +55,7 @@ struct DevCounts {           // device-side counters; copied into gsplat_counts
     int32_t n_survivors, n_visible;
     int64_t n_pairs;         // the reference's (tile, Gaussian) pairs (F11)
     int32_t max_tiles, reserved;
-    int64_t n_binned;        // (half-tile list, Gaussian) pairs actually binned
+    int64_t n_binned;        // (list, Gaussian) pairs actually binned
 };
 static_assert(sizeof(DevCounts) == sizeof(gsplat_counts), "counts layout");
 
@@ -71,7 +71,7 @@ struct CounterBlock {
     uint32_t pad[15];
 };
 
-// A "list" is the depth-ordered set of Gaussians of one HALF tile (16 x 8 pixels): the unit one wave64 rasterises.
+// A "list" is the depth-ordered set of Gaussians of one 16 x 8-pixel region: the unit one wave64 rasterises.
 // Binning is a two-level counting sort: (list, Gaussian) pairs go to coarse bins of 64 consecutive lists first
 // (bin_count_kernel / bin_scatter_kernel, blocks of 2048 Gaussians with an LDS histogram, one global atomic per block and
 // bin), then every bin is split into its 64 lists (split_count_kernel / split_scatter_kernel), then every list is sorted by depth.
@@ -281,7 +281,7 @@ __device__ __forceinline__ void stage_geometry(ProjectLds& s, const gsplat_gauss
     }
 }
 
-// Calls f(list, ordinal, a, b) for every half-tile list of a Gaussian's rectangle whose mask bit is set (row-major;
+// Calls f(list, ordinal, a, b) for every list of a Gaussian's rectangle whose mask bit is set (row-major;
 // ordinal 0 .. nt - 1 counts the calls; a, b = the owning lane's values).  Rectangles of up to 32 lists: each lane walks
 // its own; larger ones (huge Gaussians: up to 32 x 64 lists; never masked) are walked by the whole wave, one after the
 // other.  Call with all 64 lanes active.
