@@ -292,7 +292,7 @@ def main():
     gimg = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(1)).to(dev)
     cam_args = (H, W, cam["fx"], cam["fy"], cam["cx"], cam["cy"])
 
-    info = {"allreduce": None}
+    info = {}
 
     def checked(fn):
         # the way training.Trainer.step renders: no wait for the frame's pair count (buffers sized from earlier frames, SH colour
@@ -313,10 +313,11 @@ def main():
     def local_step():
         checked(render_pass)
 
-    def step():
+    def step(mode=None):
+        mode = mode or args.exchange
         if not need_grad or world == 1:
             return local_step()
-        if args.exchange == "factored":
+        if mode == "factored":
             def factored_pass():
                 for p in params.values():
                     p.grad = None
@@ -328,12 +329,13 @@ def main():
             # on a repeat across the ranks)
             ex = checked(factored_pass)
             ex.finish()
-            info["allreduce"] = "factored: all-reduce of pos/opacity/scale/rotation gradients (44 B per Gaussian) + all-gather " \
+            info[mode] = "factored: all-reduce of pos/opacity/scale/rotation gradients (44 B per Gaussian) + all-gather " \
                                 "of colour-logit gradients (12 B per Gaussian and view) + local SH rebuild"
         else:
             checked(render_pass)
             grads = [params[k].grad for k in NAMES]
-            info["allreduce"] = "one flat buffer, single collective" if dp._common_base(grads) is not None else "2 buckets"
+            info[mode] = "all-reduce of all six gradient tensors (236 B per Gaussian): " + \
+                         ("one flat buffer, single collective" if dp._common_base(grads) is not None else "2 buckets")
             dp.allreduce_gradients(grads, world_views=world)
 
     def fence():
@@ -403,8 +405,18 @@ def main():
             for _ in range(2):
                 collectives()
             alone_ms = max_over_ranks(timed(collectives, args.steps, fence))
+        # the other form of the exchange, same step (both are built; the first run on real links decides which is the default)
+        alt = "allreduce" if args.exchange == "factored" else "factored"
+        alt_ms = alt_err = None
+        try:
+            for _ in range(2):
+                step(alt)
+            alt_ms = max_over_ranks(timed(lambda: step(alt), args.steps, fence))
+        except Exception as e:                           # never take the headline line down
+            alt_err = f"{type(e).__name__}: {e}"
         extras["exchange"] = {
             "mode": args.exchange, "nranks": dist.get_world_size(), "backend": dist.get_backend(),
+            "other_mode": {"mode": alt, "what": info.get(alt), "step_ms": alt_ms, "error": alt_err},
             "step_ms": ms, "compute_ms": compute_ms, "exchange_ms": ms - compute_ms, "exchange_alone_ms": alone_ms,
             "allreduce_bytes_per_step": (44 if args.exchange == "factored" else 236) * N,
             "allgather_bytes_per_rank_per_step": 12 * N if args.exchange == "factored" else 0,
@@ -437,7 +449,7 @@ def main():
                                    f"{'forward+backward' if need_grad else 'forward only'}, one camera view per GPU per step"
                                    + (", gradient exchange over RCCL" if world > 1 and need_grad else ""),
                        "N": N, "V": V, "P": P, "tiles": math.ceil(H / 16) * math.ceil(W / 16),
-                       "parallelism": f"dp{world} by camera view", "allreduce": info["allreduce"],
+                       "parallelism": f"dp{world} by camera view", "allreduce": info.get(args.exchange),
                        "counts": "waited for in every forward pass" if args.wait_counts else
                                  "not waited for: buffers from earlier frames, checks once per step (ops.deferred_checks, as Trainer.step)"},
             "fps": world * args.steps / elapsed,
