@@ -1175,7 +1175,7 @@ __device__ __forceinline__ float all_reduce8(float x) {
 
 // backward: longest queue per chunk (sizes the slot block below).  Measured at 16 / 20 / 24 / 28 / 32: 253 / 249-258 / 247 / 249 / 269 us
 // (config 3): below 12.8 KB of LDS per wave the occupancy gain is eaten by chunks cut short.
-constexpr int MAXQ_BWD = 28;
+constexpr int MAXQ_BWD = 28;                          // (even: the loop evaluates entries in pairs)
 
 // LDS of the backward kernel.  LDS float atomics are slow on this hardware (a ds_add_f32 wave-instruction with 64 lanes cost
 // ~100 LDS cycles here: 230 us of a 450 us kernel), so nothing is accumulated with them: every group writes the nine sums of
@@ -1278,20 +1278,9 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
         ++st_chunks;
         st_visited += (uint32_t)maxc;
         int kdone = 0;                       // iterations executed (uniform): slots [0, kdone) of every queue are valid
-        // software pipeline over the queue (LDS latency is not covered by occupancy here: 2-3 waves per SIMD): the record of
-        // iteration k + 1 and the queue entry of iteration k + 2 are requested before iteration k is evaluated
-        uint32_t o_nx = myq[0];
-        f4 a_nx = lds_at(s.r0, o_nx), b_nx = lds_at(s.r1, o_nx);
-        float cb_nx = lds_at(reinterpret_cast<const float*>(s.r2), o_nx);
-        o_nx = myq[1];
-        for (int k0 = 0; k0 < maxc; k0 += 8) {
-          const int k1 = min(k0 + 8, maxc);
-          for (int k = k0; k < k1; ++k) {
-            const f4 a = a_nx, b = b_nx;
-            const float cbl = cb_nx, go = b.y;
-            a_nx = lds_at(s.r0, o_nx); b_nx = lds_at(s.r1, o_nx);                   // null record past the end of the queue
-            cb_nx = lds_at(reinterpret_cast<const float*>(s.r2), o_nx);
-            o_nx = myq[k + 2];                                                       // k + 2 < QCAP
+        // One queue entry: the group's 16 pixels against one Gaussian; the nine sums go to slot k of the group's queue.
+        auto entry = [&](const f4& a, const f4& b, const float cbl, const int k) {
+            const float go = b.y;
             const float du = fpx - a.x;
             const v2f dv = fpy - a.y;
             const float c0 = a.z * du * du, c1 = a.w * du;
@@ -1303,8 +1292,9 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
             const v2f og = go * g;
             // alpha = min(o g, alpha_max) where q <= chi and that is >= alpha_cutoff (<=> o g >= alpha_cutoff: cutoff <= alpha_max), else 0
             const bool p0 = i0 && og.x >= alpha_cutoff, p1 = i1 && og.y >= alpha_cutoff;
+            const float cl0 = vmin(og.x, amax), cl1 = vmin(og.y, amax);                 // (unconditional: a select, not a branch)
             v2f al;
-            al.x = p0 ? vmin(og.x, amax) : 0.0f; al.y = p1 ? vmin(og.y, amax) : 0.0f;
+            al.x = p0 ? cl0 : 0.0f; al.y = p1 ? cl1 : 0.0f;
             const bool alive0 = T.x > 5e-5f, alive1 = T.y > 5e-5f;
             v2f w = al * T;
             w.x = alive0 ? w.x : 0.0f; w.y = alive1 ? w.y : 0.0f;
@@ -1335,6 +1325,22 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
             myslot[k * 9] = reduce_scatter8(r, lane);
             if (j == 0) myslot[k * 9 + 8] = tot_b;
             T = T - al * T;
+        };
+        // Software pipeline over the queue (LDS latency is not covered by occupancy here: 3 waves per SIMD), two entries per step
+        // in two register sets: entry k + 2 is requested into set 0 as soon as entry k has been evaluated from it, while entry
+        // k + 1 is evaluated from set 1, and so on -- no register copies.  An odd queue ends on a null record (its slot gets zeros).
+        const float* r2f = reinterpret_cast<const float*>(s.r2);
+        uint32_t oo = *reinterpret_cast<const uint32_t*>(myq);
+        f4 a0 = lds_at(s.r0, oo & 0xFFFFu), b0 = lds_at(s.r1, oo & 0xFFFFu), a1 = lds_at(s.r0, oo >> 16), b1 = lds_at(s.r1, oo >> 16);
+        float cb0 = lds_at(r2f, oo & 0xFFFFu), cb1 = lds_at(r2f, oo >> 16);
+        for (int k0 = 0; k0 < maxc; k0 += 8) {
+          const int k1 = min(k0 + 8, maxc);
+          for (int k = k0; k < k1; k += 2) {
+            oo = *reinterpret_cast<const uint32_t*>(myq + k + 2);                       // entries k + 2, k + 3 (null past the end; k + 3 < QCAP)
+            entry(a0, b0, cb0, k);
+            a0 = lds_at(s.r0, oo & 0xFFFFu); b0 = lds_at(s.r1, oo & 0xFFFFu); cb0 = lds_at(r2f, oo & 0xFFFFu);
+            entry(a1, b1, cb1, k + 1);
+            a1 = lds_at(s.r0, oo >> 16); b1 = lds_at(s.r1, oo >> 16); cb1 = lds_at(r2f, oo >> 16);
           }
           kdone = k1;
           if (!__any(T.x > 5e-5f || T.y > 5e-5f)) break;          // every 8 entries: all pixels dead
