@@ -20,6 +20,7 @@ Extra objects on the line:
   cpu_baseline  the CPU oracle (oracle/torch_port.py, the reference's PyTorch CPU path restated) timed on this box's
                 host cores on a bounded sample: a CROP of the frame (rank 0, N = 1 only).  A reported baseline, not the target.
   sustained     >= 1 s of back-to-back steps after the timed region: ms/step mean, min and max over 10 windows.
+  waiting_path  the same step through the call that waits for every frame's pair count (the reference-style call).
   N = 1 extras  (outside the timed region; --no-extras skips them) forward_only (the reference's FPS protocol,
                 scripts/render_trained.py:319-381: frame by frame, and software-pipelined render_frames), train_step
                 (render + L1/SSIM loss + backward + clip + Adam, scripts/train.py:446-569), config4 (3 M Gaussians, a training iteration
@@ -384,6 +385,16 @@ def main():
         wins = [max_over_ranks(timed(step, per, fence)) for _ in range(10)]
         extras["sustained"] = {"seconds": sum(wins) * per / 1e3, "steps": 10 * per, "ms_per_step": sum(wins) / 10, "min_ms": min(wins),
                                "max_ms": max(wins), "windows": 10}
+    if not args.no_extras and not args.wait_counts and world == 1:
+        # the same step through the call that WAITS for every frame's pair count in the middle of the forward pass (exact buffers,
+        # exceptions raised by the call itself: what a caller that only switched the import gets)
+        def waiting_step():
+            render_pass()
+        for _ in range(3):
+            waiting_step()
+        wms = timed(waiting_step, max(20, args.steps // 4), fence)
+        extras["waiting_path"] = {"what": "render_gaussians() outside deferred_checks(): the host waits for the frame's counters",
+                                  "ms_per_step": wms, "mpix_per_s": H * W / (wms * 1e-3) / 1e6}
     if world > 1 and need_grad:
         # the same step without the exchange, and the collectives alone, on buffers of the step's sizes
         compute_ms = max_over_ranks(timed(local_step, args.steps, fence))
