@@ -458,7 +458,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"SURVEY §8d config {args.config}: {N} Gaussians, {W}x{H}, SH degree 3, "
                                    f"{'forward+backward' if need_grad else 'forward only'}, one camera view per GPU per step"
-                                   + (", gradient exchange over RCCL" if world > 1 and need_grad else ""),
+                                   + ((", gradient exchange over " + ("RCCL" if args.backend == "nccl" else args.backend + " (rehearsal)"))
+                                      if world > 1 and need_grad else ""),
                        "N": N, "V": V, "P": P, "tiles": math.ceil(H / 16) * math.ceil(W / 16),
                        "parallelism": f"dp{world} by camera view", "allreduce": info.get(args.exchange),
                        "counts": "waited for in every forward pass" if args.wait_counts else
