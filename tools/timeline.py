@@ -5,7 +5,7 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-cams = [i for i, r in enumerate(rows) if 'camera_kernel' in r['Kernel_Name']]
+cams = [i for i, r in enumerate(rows) if 'project_kernel' in r['Kernel_Name']]      # the first kernel of every step
 a, b = cams[-3], cams[-2]
 t0 = int(rows[a]['Start_Timestamp'])
 prev = t0
