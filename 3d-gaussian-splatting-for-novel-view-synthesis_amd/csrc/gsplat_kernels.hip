@@ -763,9 +763,12 @@ __global__ __launch_bounds__(T) void list_sort_kernel(const uint32_t* __restrict
     __shared__ uint32_t cnt[B + T];                               // padded: counter c lives at c + c / CPT (conflict-free scan)
     __shared__ uint32_t red[4 + T / 64];
     const uint32_t lo = cls ? class_bounds[cls - 1] : 0u, hi = class_bounds[cls];
-    if (lo + blockIdx.x >= hi) return;
     const int tid = threadIdx.x;
-    const uint2 rg = ranges[order[lo + blockIdx.x]];
+    // grid-stride over the class's lists: the grid is sized for the chip, not for the worst-case number of lists of the class
+    // (a workgroup of the 100 KB class occupies a whole CU even when it only finds out that it has nothing to do)
+    for (uint32_t b = blockIdx.x; lo + b < hi; b += gridDim.x) {
+    __syncthreads();                                              // the LDS arrays are reused from list to list
+    const uint2 rg = ranges[order[lo + b]];
     const uint32_t n = rg.y - rg.x;                               // 1 <= n; n < CAP by the class bounds, except in class 0
     uint64_t* __restrict__ g = vals + rg.x;
     uint32_t* __restrict__ out = sorted_ids + rg.x;
@@ -777,7 +780,7 @@ __global__ __launch_bounds__(T) void list_sort_kernel(const uint32_t* __restrict
             if (a > b) { g[i] = b; g[l] = a; }
         });
         for (uint32_t i = tid; i < n; i += T) out[i] = (uint32_t)g[i] & ID_MASK;
-        return;
+        continue;
     }
 #define PADC(c) ((c) + ((c) >> LOG2CPT))
     uint64_t key[E];
@@ -840,7 +843,7 @@ __global__ __launch_bounds__(T) void list_sort_kernel(const uint32_t* __restrict
             if (a > b) { sk[i] = b; sk[l] = a; }
         });
         for (uint32_t i = tid; i < n; i += T) out[i] = (uint32_t)sk[i] & ID_MASK;
-        return;
+        continue;
     }
 #pragma unroll
     for (int k = 0; k < CPT; ++k) cnt[tid * (CPT + 1) + k] = toff + loc[k];
@@ -864,6 +867,7 @@ __global__ __launch_bounds__(T) void list_sort_kernel(const uint32_t* __restrict
             for (uint32_t q = s; q < en; ++q) r += sk[q] < k ? 1u : 0u;
             out[r] = (uint32_t)k & ID_MASK;
         }
+    }
     }
 #undef PADC
 }
@@ -1796,16 +1800,16 @@ int gsplat_bin(int64_t n, int64_t pair_capacity, const gsplat_view* v, const voi
     uint64_t* vals = sc.vals;
     const auto cap = [&](int64_t min_len) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(nl, n_binned / min_len)); };
     if (n_binned >= 1024) {       // lists of 1024+ entries: 100 KB of LDS per workgroup; 8192+ fall back to global memory inside
-        hipLaunchKernelGGL((list_sort_kernel<512, 16, 13>), dim3(cap(1024)), dim3(512), 0, st, ps.order, ps.class_bounds, 0, ps.ranges,
+        hipLaunchKernelGGL((list_sort_kernel<512, 16, 13>), dim3(std::min(cap(1024), 256u)), dim3(512), 0, st, ps.order, ps.class_bounds, 0, ps.ranges,
                            vals, sorted_ids);
         LAUNCH_CHECK("list_sort_kernel<8192>");
     }
     if (n_binned >= 256) {
-        hipLaunchKernelGGL((list_sort_kernel<256, 4, 11>), dim3(cap(256)), dim3(256), 0, st, ps.order, ps.class_bounds, 1, ps.ranges,
+        hipLaunchKernelGGL((list_sort_kernel<256, 4, 11>), dim3(std::min(cap(256), 4096u)), dim3(256), 0, st, ps.order, ps.class_bounds, 1, ps.ranges,
                            vals, sorted_ids);
         LAUNCH_CHECK("list_sort_kernel<1024>");
     }
-    hipLaunchKernelGGL((list_sort_kernel<64, 4, 9>), dim3(cap(1)), dim3(64), 0, st, ps.order, ps.class_bounds, 2, ps.ranges, vals,
+    hipLaunchKernelGGL((list_sort_kernel<64, 4, 9>), dim3(std::min(cap(1), 65536u)), dim3(64), 0, st, ps.order, ps.class_bounds, 2, ps.ranges, vals,
                        sorted_ids);
     LAUNCH_CHECK("list_sort_kernel<256>");
     return GSPLAT_OK;
