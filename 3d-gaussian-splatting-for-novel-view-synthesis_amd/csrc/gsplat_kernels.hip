@@ -605,46 +605,6 @@ __global__ __launch_bounds__(256) void split_count_kernel(int nb, const uint32_t
     }
 }
 
-__global__ __launch_bounds__(256) void split_scatter_kernel(int nl, int nb, const uint32_t* __restrict__ bin_start,
-                                                            const uint64_t* __restrict__ bvals, uint32_t capacity,
-                                                            const DevCounts* __restrict__ counts,
-                                                            const uint32_t* __restrict__ list_count, const uint32_t* __restrict__ seg_off,
-                                                            uint2* __restrict__ ranges, uint64_t* __restrict__ vals) {
-    constexpr int L = 1 << BIN_SHIFT, U = SPLIT_CHUNK / 256;
-    __shared__ uint32_t cur[L];
-    const int tid = threadIdx.x;
-    const uint32_t n_binned = pairs_to_process(counts, capacity);
-    const uint32_t c0 = blockIdx.x * (uint32_t)SPLIT_CHUNK, c1 = min(c0 + (uint32_t)SPLIT_CHUNK, n_binned);
-    if (c0 >= n_binned) return;
-    for (int b = bin_of_pair(bin_start, nb, c0); b < nb && bin_start[b] < c1; ++b) {
-        const uint32_t bs = bin_start[b], s = max(c0, bs), e = min(c1, bin_start[b + 1]);
-        if (s >= e) continue;
-        if (tid < L) {                                          // one wave: exclusive scan of the bin's 64 list sizes
-            const uint32_t c = list_count[b * L + tid];
-            uint32_t incl = c;
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t up_ = (uint32_t)__shfl_up((int)incl, d);
-                if (tid >= d) incl += up_;
-            }
-            const uint32_t st = bs + incl - c;
-            cur[tid] = st + seg_off[((int64_t)blockIdx.x + b) * L + tid];      // garbage where the segment has no pair: unused
-            const int list = b * L + tid;
-            if (s == bs && list < nl) ranges[list] = uint2{min(st, capacity), min(st + c, capacity)};    // (clipped: overflow only)
-        }
-        __syncthreads();
-        uint64_t v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = s + u * 256 + tid < e ? bvals[s + u * 256 + tid] : ~0ull;
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (s + u * 256 + tid < e) {
-                const uint32_t pos = atomicAdd(&cur[local_list(v[u])], 1u);
-                if (pos < n_binned) vals[pos] = v[u];
-            }
-        __syncthreads();
-    }
-}
-
 // ---- K5: plan ----------------------------------------------------------------------------------------
 // Longest-processing-time-first launch order of the lists (1/8-octave buckets of the list length: the raster kernels
 // are tail-bound, a few dense lists take 5x the mean, so they must start first), and the boundaries of the sort size
@@ -660,30 +620,31 @@ __device__ __forceinline__ uint32_t class_first_bucket(int c) { return c == 0 ? 
 // Counting sort of the lists by work bucket, descending.  Same-address LDS atomics serialise and neighbouring lists
 // often share a bucket, so every bucket has 16 sub-counters selected by the lane (flat index = (255 - bucket) * 16 + sub:
 // ascending flat index = descending bucket).
-__global__ __launch_bounds__(1024) void plan_kernel(int nl, const uint2* __restrict__ ranges, uint32_t* __restrict__ order,
-                                                    uint32_t* __restrict__ class_bounds) {
-    constexpr int SUB = 16, NF = 256 * SUB, K = 16;          // K lists per thread and round, held in registers
-    __shared__ uint32_t cnt[NF], wsum[16];
+template <int THREADS, class Len>
+__device__ __forceinline__ void plan_body(int nl, Len len, uint32_t* __restrict__ order, uint32_t* __restrict__ class_bounds,
+                                          uint32_t* cnt, uint32_t* wsum) {
+    constexpr int SUB = 16, NF = 256 * SUB, K = 16384 / THREADS, CPT = NF / THREADS, WAVES = THREADS / 64;
+    // K lists per thread and round, held in registers; CPT counters per thread in the scan
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = tid & (SUB - 1);
-    for (int f = tid; f < NF; f += 1024) cnt[f] = 0u;
+    for (int f = tid; f < NF; f += THREADS) cnt[f] = 0u;
     __syncthreads();
-    const bool one_round = nl <= 1024 * K;
-    uint32_t flat[K];                                          // counter index of list (round base + k * 1024 + tid), or ~0
-    for (int base = 0; base < nl; base += 1024 * K) {
-        uint2 rg[K];
+    const bool one_round = nl <= THREADS * K;
+    uint32_t flat[K];                                          // counter index of list (round base + k * THREADS + tid), or ~0
+    for (int base = 0; base < nl; base += THREADS * K) {
+        uint32_t w[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) rg[k] = base + k * 1024 + tid < nl ? ranges[base + k * 1024 + tid] : uint2{0u, 0u};
+        for (int k = 0; k < K; ++k) w[k] = base + k * THREADS + tid < nl ? len(base + k * THREADS + tid) : 0u;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            flat[k] = base + k * 1024 + tid < nl ? (255u - work_bucket(rg[k].y - rg[k].x)) * SUB + sub : 0xFFFFFFFFu;
+            flat[k] = base + k * THREADS + tid < nl ? (255u - work_bucket(w[k])) * SUB + sub : 0xFFFFFFFFu;
             if (flat[k] != 0xFFFFFFFFu) atomicAdd(&cnt[flat[k]], 1u);
         }
     }
     __syncthreads();
-    // exclusive prefix over the NF counters: thread t owns 4 consecutive ones
-    uint32_t c[4], run = 0u;
+    // exclusive prefix over the NF counters: thread t owns CPT consecutive ones
+    uint32_t c[CPT], run = 0u;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { c[k] = cnt[tid * 4 + k]; run += c[k]; }
+    for (int k = 0; k < CPT; ++k) { c[k] = cnt[tid * CPT + k]; run += c[k]; }
     uint32_t incl = run;
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t up_ = (uint32_t)__shfl_up((int)incl, d);
@@ -694,23 +655,85 @@ __global__ __launch_bounds__(1024) void plan_kernel(int nl, const uint2* __restr
     uint32_t st = incl - run;
     for (int k = 0; k < wave; ++k) st += wsum[k];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { cnt[tid * 4 + k] = st; st += c[k]; }
+    for (int k = 0; k < CPT; ++k) { cnt[tid * CPT + k] = st; st += c[k]; }
     __syncthreads();
     // lists in buckets >= first bucket of a class = prefix at the first sub-counter of the bucket below it
     if (tid < SORT_CLASSES) class_bounds[tid] = cnt[(256u - class_first_bucket(tid)) * SUB];
     __syncthreads();
-    for (int base = 0; base < nl; base += 1024 * K) {
+    for (int base = 0; base < nl; base += THREADS * K) {
         if (!one_round) {                                      // more than 16384 lists: recompute the counter indices
-            uint2 rg[K];
+            uint32_t w[K];
 #pragma unroll
-            for (int k = 0; k < K; ++k) rg[k] = base + k * 1024 + tid < nl ? ranges[base + k * 1024 + tid] : uint2{0u, 0u};
+            for (int k = 0; k < K; ++k) w[k] = base + k * THREADS + tid < nl ? len(base + k * THREADS + tid) : 0u;
 #pragma unroll
             for (int k = 0; k < K; ++k)
-                flat[k] = base + k * 1024 + tid < nl ? (255u - work_bucket(rg[k].y - rg[k].x)) * SUB + sub : 0xFFFFFFFFu;
+                flat[k] = base + k * THREADS + tid < nl ? (255u - work_bucket(w[k])) * SUB + sub : 0xFFFFFFFFu;
         }
 #pragma unroll
         for (int k = 0; k < K; ++k)
-            if (flat[k] != 0xFFFFFFFFu) order[atomicAdd(&cnt[flat[k]], 1u)] = (uint32_t)(base + k * 1024 + tid);
+            if (flat[k] != 0xFFFFFFFFu) order[atomicAdd(&cnt[flat[k]], 1u)] = (uint32_t)(base + k * THREADS + tid);
+    }
+    (void)WAVES;
+}
+constexpr int PLAN_LDS_WORDS = 256 * 16 + 16;
+
+// the plan by itself: only when there is nothing to bin (all ranges empty)
+__global__ __launch_bounds__(1024) void plan_kernel(int nl, const uint2* __restrict__ ranges, uint32_t* __restrict__ order,
+                                                    uint32_t* __restrict__ class_bounds) {
+    __shared__ uint32_t lds[PLAN_LDS_WORDS];
+    plan_body<1024>(nl, [&](int l) { const uint2 r = ranges[l]; return r.y - r.x; }, order, class_bounds, lds, lds + 256 * 16);
+}
+
+// ---- K3c, second half (after the plan it carries) ----------------------------------------------------
+// Block 0 does not scatter: it is the PLAN (the list lengths are final after split_count_kernel, and a one-workgroup kernel of
+// its own was 13 us of latency at config 3; here it runs beside the scatter).
+#ifndef SS_THREADS
+#define SS_THREADS 1024
+#endif
+__global__ __launch_bounds__(SS_THREADS) void split_scatter_kernel(int nl, int nb, const uint32_t* __restrict__ bin_start,
+                                                            const uint64_t* __restrict__ bvals, uint32_t capacity,
+                                                            const DevCounts* __restrict__ counts,
+                                                            const uint32_t* __restrict__ list_count, const uint32_t* __restrict__ seg_off,
+                                                            uint2* __restrict__ ranges, uint64_t* __restrict__ vals,
+                                                            uint32_t* __restrict__ order, uint32_t* __restrict__ class_bounds) {
+    constexpr int L = 1 << BIN_SHIFT, U = SPLIT_CHUNK / SS_THREADS;
+    __shared__ uint32_t lds[PLAN_LDS_WORDS];
+    if (blockIdx.x == 0) {
+        plan_body<SS_THREADS>(nl, [&](int l) { return list_count[l]; }, order, class_bounds, lds, lds + 256 * 16);
+        return;
+    }
+    uint32_t* const cur = lds;                               // [L]
+    const int tid = threadIdx.x;
+    const uint32_t n_binned = pairs_to_process(counts, capacity);
+    const uint32_t chunk = blockIdx.x - 1u;
+    const uint32_t c0 = chunk * (uint32_t)SPLIT_CHUNK, c1 = min(c0 + (uint32_t)SPLIT_CHUNK, n_binned);
+    if (c0 >= n_binned) return;
+    for (int b = bin_of_pair(bin_start, nb, c0); b < nb && bin_start[b] < c1; ++b) {
+        const uint32_t bs = bin_start[b], s = max(c0, bs), e = min(c1, bin_start[b + 1]);
+        if (s >= e) continue;
+        if (tid < L) {                                          // one wave: exclusive scan of the bin's 64 list sizes
+            const uint32_t c = list_count[b * L + tid];
+            uint32_t incl = c;
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t up_ = (uint32_t)__shfl_up((int)incl, d);
+                if (tid >= d) incl += up_;
+            }
+            const uint32_t st = bs + incl - c;
+            cur[tid] = st + seg_off[((int64_t)chunk + b) * L + tid];           // garbage where the segment has no pair: unused
+            const int list = b * L + tid;
+            if (s == bs && list < nl) ranges[list] = uint2{min(st, capacity), min(st + c, capacity)};    // (clipped: overflow only)
+        }
+        __syncthreads();
+        uint64_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = s + u * SS_THREADS + tid < e ? bvals[s + u * SS_THREADS + tid] : ~0ull;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (s + u * SS_THREADS + tid < e) {
+                const uint32_t pos = atomicAdd(&cur[local_list(v[u])], 1u);
+                if (pos < n_binned) vals[pos] = v[u];
+            }
+        __syncthreads();
     }
 }
 
@@ -728,7 +751,21 @@ __global__ __launch_bounds__(1024) void plan_kernel(int nl, const uint2* __restr
 // Direction-free bitonic network: every merge of size k starts with a mirror step (i <-> block_end - i), followed by
 // the half-cleaner steps j = k/4 .. 1; every compare-exchange puts the smaller key at the lower index.  With virtual
 // +inf padding above n no real element is ever exchanged with the padding, so the network also runs in place.
-template <int THREADS, class Swap>
+// Synchronisation of the threads that sort one list: the workgroup, or -- when a wave sorts a list by itself inside a larger
+// workgroup -- nothing but the order of the wave's own LDS instructions (the LDS executes one wave's instructions in issue
+// order; the fences keep the compiler from moving accesses across).
+template <bool WAVE>
+__device__ __forceinline__ void group_sync() {
+    if (WAVE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+template <int THREADS, bool WAVE, class Swap>
 __device__ __forceinline__ void bitonic_network(uint32_t n, uint32_t m, int tid, Swap swap_if_greater) {
     uint32_t lk = 1;                                              // log2(k)
     for (uint32_t k = 2; k <= m; k <<= 1, ++lk) {
@@ -737,7 +774,7 @@ __device__ __forceinline__ void bitonic_network(uint32_t n, uint32_t m, int tid,
             const uint32_t r = t & (half - 1), i = ((t >> lh) << lk) + r, l = i + (k - 1 - 2 * r);
             if (l < n) swap_if_greater(i, l);
         }
-        __syncthreads();
+        group_sync<WAVE>();
         uint32_t lj = lh;                                         // log2(j) + 1
         for (uint32_t j = half >> 1; j > 0; j >>= 1) {
             --lj;
@@ -745,42 +782,50 @@ __device__ __forceinline__ void bitonic_network(uint32_t n, uint32_t m, int tid,
                 const uint32_t i = ((t >> lj) << (lj + 1)) + (t & (j - 1)), l = i + j;
                 if (l < n) swap_if_greater(i, l);
             }
-            __syncthreads();
+            group_sync<WAVE>();
         }
     }
 }
 
 constexpr uint32_t DENSE_BUCKET = 48;
 
+// LDS of one sorting group: T threads, lists shorter than T * E, 2^LOG2B depth buckets
 template <int T, int E, int LOG2B>
-__global__ __launch_bounds__(T) void list_sort_kernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ class_bounds,
-                                                      int cls, const uint2* __restrict__ ranges, uint64_t* __restrict__ vals,
-                                                      uint32_t* __restrict__ sorted_ids) {
+struct SortLds {
+    uint64_t sk[T * E];
+    uint32_t cnt[(1 << LOG2B) + T];                               // padded: counter c lives at c + c / CPT (conflict-free scan)
+    uint32_t red[4 + T / 64];
+};
+
+// Sort one list: T threads (`tid` = index inside the group).  WAVE: the group is one wave of a larger workgroup (T = 64).
+// GLOBAL: lists of T * E entries and more are sorted in place in global memory (only the class of the longest lists has them).
+template <int T, int E, int LOG2B, bool WAVE, bool GLOBAL>
+__device__ __forceinline__ void sort_list(SortLds<T, E, LOG2B>& s, int tid, uint2 rg, uint64_t* __restrict__ vals,
+                                          uint32_t* __restrict__ sorted_ids) {
+    static_assert(!WAVE || T == 64, "a wave-synchronised group is one wave");
     constexpr int CAP = T * E, B = 1 << LOG2B, CPT = B / T;       // CPT counters per thread in the scan
     static_assert((CPT & (CPT - 1)) == 0 && CPT >= 2, "B / T must be a power of two");
     constexpr int LOG2CPT = __builtin_ctz(CPT);
-    __shared__ uint64_t sk[CAP];
-    __shared__ uint32_t cnt[B + T];                               // padded: counter c lives at c + c / CPT (conflict-free scan)
-    __shared__ uint32_t red[4 + T / 64];
-    const uint32_t lo = cls ? class_bounds[cls - 1] : 0u, hi = class_bounds[cls];
-    const int tid = threadIdx.x;
-    // grid-stride over the class's lists: the grid is sized for the chip, not for the worst-case number of lists of the class
-    // (a workgroup of the 100 KB class occupies a whole CU even when it only finds out that it has nothing to do)
-    for (uint32_t b = blockIdx.x; lo + b < hi; b += gridDim.x) {
-    __syncthreads();                                              // the LDS arrays are reused from list to list
-    const uint2 rg = ranges[order[lo + b]];
-    const uint32_t n = rg.y - rg.x;                               // 1 <= n; n < CAP by the class bounds, except in class 0
+    uint64_t* const sk = s.sk;
+    uint32_t* const cnt = s.cnt;
+    uint32_t* const red = s.red;
+    group_sync<WAVE>();                                           // the LDS arrays are reused from list to list
+    uint32_t n = rg.y - rg.x;                                     // 1 <= n; n < CAP by the class bounds, except in the GLOBAL class
     uint64_t* __restrict__ g = vals + rg.x;
     uint32_t* __restrict__ out = sorted_ids + rg.x;
-    if (n >= (uint32_t)CAP) {                                     // class 0 only: longer than the LDS holds -> in place in global memory
-        uint32_t m = 2;
-        while (m < n) m <<= 1;
-        bitonic_network<T>(n, m, tid, [&](uint32_t i, uint32_t l) {
-            const uint64_t a = g[i], b = g[l];
-            if (a > b) { g[i] = b; g[l] = a; }
-        });
-        for (uint32_t i = tid; i < n; i += T) out[i] = (uint32_t)g[i] & ID_MASK;
-        continue;
+    if (n >= (uint32_t)CAP) {
+        if (!GLOBAL) {
+            n = CAP - 1;                                          // cannot happen (class bounds); memory-safe if it ever did
+        } else {                                                  // longer than the LDS holds -> in place in global memory
+            uint32_t m = 2;
+            while (m < n) m <<= 1;
+            bitonic_network<T, false>(n, m, tid, [&](uint32_t i, uint32_t l) {
+                const uint64_t a = g[i], b = g[l];
+                if (a > b) { g[i] = b; g[l] = a; }
+            });
+            for (uint32_t i = tid; i < n; i += T) out[i] = (uint32_t)g[i] & ID_MASK;
+            return;
+        }
     }
 #define PADC(c) ((c) + ((c) >> LOG2CPT))
     uint64_t key[E];
@@ -797,9 +842,9 @@ __global__ __launch_bounds__(T) void list_sort_kernel(const uint32_t* __restrict
         mn = min(mn, (uint32_t)__shfl_xor((int)mn, sft));
         mx = max(mx, (uint32_t)__shfl_xor((int)mx, sft));
     }
-    __syncthreads();
+    group_sync<WAVE>();
     if ((tid & 63) == 0) { atomicMin(&red[0], mn); atomicMax(&red[1], mx); }
-    __syncthreads();
+    group_sync<WAVE>();
     mn = red[0];
     const uint32_t range = red[1] - mn;
     const int bl = range ? 32 - __clz((int)range) : 0;
@@ -810,7 +855,7 @@ __global__ __launch_bounds__(T) void list_sort_kernel(const uint32_t* __restrict
             const uint32_t b = ((uint32_t)(key[e] >> 32) - mn) >> shift;
             atomicAdd(&cnt[PADC(b)], 1u);
         }
-    __syncthreads();
+    group_sync<WAVE>();
     // exclusive scan of the B counters: thread t owns counters [t CPT, (t + 1) CPT)
     uint32_t loc[CPT], run = 0u, big = 0u;
 #pragma unroll
@@ -828,7 +873,7 @@ __global__ __launch_bounds__(T) void list_sort_kernel(const uint32_t* __restrict
     for (int sft = 32; sft > 0; sft >>= 1) big = max(big, (uint32_t)__shfl_xor((int)big, sft));
     if ((tid & 63) == 63) red[4 + (tid >> 6)] = incl;
     if ((tid & 63) == 0) atomicMax(&red[2], big);
-    __syncthreads();
+    group_sync<WAVE>();
     uint32_t toff = incl - run;
     for (int k = 0; k < (tid >> 6); ++k) toff += red[4 + k];
     if (red[2] > DENSE_BUCKET) {                                  // clustered depths: exact fallback (uniform branch)
@@ -837,24 +882,24 @@ __global__ __launch_bounds__(T) void list_sort_kernel(const uint32_t* __restrict
             if ((uint32_t)(e * T + tid) < n) sk[e * T + tid] = key[e];
         uint32_t m = 2;
         while (m < n) m <<= 1;
-        __syncthreads();
-        bitonic_network<T>(n, m, tid, [&](uint32_t i, uint32_t l) {
+        group_sync<WAVE>();
+        bitonic_network<T, WAVE>(n, m, tid, [&](uint32_t i, uint32_t l) {
             const uint64_t a = sk[i], b = sk[l];
             if (a > b) { sk[i] = b; sk[l] = a; }
         });
         for (uint32_t i = tid; i < n; i += T) out[i] = (uint32_t)sk[i] & ID_MASK;
-        continue;
+        return;
     }
 #pragma unroll
     for (int k = 0; k < CPT; ++k) cnt[tid * (CPT + 1) + k] = toff + loc[k];
-    __syncthreads();
+    group_sync<WAVE>();
 #pragma unroll
     for (int e = 0; e < E; ++e)
         if ((uint32_t)(e * T + tid) < n) {
             const uint32_t b = ((uint32_t)(key[e] >> 32) - mn) >> shift;
             sk[atomicAdd(&cnt[PADC(b)], 1u)] = key[e];
         }
-    __syncthreads();
+    group_sync<WAVE>();
     // cnt[b] is now the END of bucket b; rank inside the bucket by counting smaller keys
 #pragma unroll
     for (int e = 0; e < E; ++e) {
@@ -862,14 +907,49 @@ __global__ __launch_bounds__(T) void list_sort_kernel(const uint32_t* __restrict
         if (p < n) {
             const uint64_t k = sk[p];
             const uint32_t b = ((uint32_t)(k >> 32) - mn) >> shift;
-            const uint32_t s = b ? cnt[PADC(b - 1u)] : 0u, en = cnt[PADC(b)];
-            uint32_t r = s;
-            for (uint32_t q = s; q < en; ++q) r += sk[q] < k ? 1u : 0u;
+            const uint32_t st = b ? cnt[PADC(b - 1u)] : 0u, en = cnt[PADC(b)];
+            uint32_t r = st;
+            for (uint32_t q = st; q < en; ++q) r += sk[q] < k ? 1u : 0u;
             out[r] = (uint32_t)k & ID_MASK;
         }
     }
-    }
 #undef PADC
+}
+
+// class 0 (lists of 1024 entries and more): one workgroup of 512 threads per list, 100 KB of LDS; grid-stride over the class's
+// lists -- the grid is sized for the chip, not for the worst-case number of lists (a workgroup of this class occupies a whole
+// CU even when it only finds out that it has nothing to do)
+template <int T, int E, int LOG2B>
+__global__ __launch_bounds__(T) void list_sort_kernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ class_bounds,
+                                                      const uint2* __restrict__ ranges, uint64_t* __restrict__ vals,
+                                                      uint32_t* __restrict__ sorted_ids) {
+    __shared__ SortLds<T, E, LOG2B> s;
+    const uint32_t hi = class_bounds[0];
+    for (uint32_t b = blockIdx.x; b < hi; b += gridDim.x)
+        sort_list<T, E, LOG2B, false, true>(s, threadIdx.x, ranges[order[b]], vals, sorted_ids);
+}
+
+// classes 1 and 2 in ONE launch (each was a latency-bound kernel of its own: 16 + 12 us at config 3, the chip half empty):
+// workgroups [0, mid_blocks) sort the lists of 256..1023 entries, one per workgroup; the others sort the short lists, one per
+// WAVE (four per workgroup, no workgroup barrier on that path).  Same LDS footprint either way (17.6 KB).
+union SortSmallLds {
+    SortLds<256, 4, 11> mid;
+    SortLds<64, 4, 9> small[4];
+};
+__global__ __launch_bounds__(256) void list_sort_small_kernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ class_bounds,
+                                                              uint32_t mid_blocks, const uint2* __restrict__ ranges,
+                                                              uint64_t* __restrict__ vals, uint32_t* __restrict__ sorted_ids) {
+    __shared__ SortSmallLds s;
+    if (blockIdx.x < mid_blocks) {
+        const uint32_t lo = class_bounds[0], hi = class_bounds[1];
+        for (uint32_t b = blockIdx.x; lo + b < hi; b += mid_blocks)
+            sort_list<256, 4, 11, false, false>(s.mid, threadIdx.x, ranges[order[lo + b]], vals, sorted_ids);
+    } else {
+        const uint32_t lo = class_bounds[1], hi = class_bounds[2];
+        const uint32_t wave = threadIdx.x >> 6, stride = (gridDim.x - mid_blocks) * 4u;
+        for (uint32_t b = (blockIdx.x - mid_blocks) * 4u + wave; lo + b < hi; b += stride)
+            sort_list<64, 4, 9, true, false>(s.small[wave], (int)(threadIdx.x & 63), ranges[order[lo + b]], vals, sorted_ids);
+    }
 }
 
 // ---- K6 / K7: rasterizer -----------------------------------------------------------------------------
@@ -1148,18 +1228,30 @@ __device__ __forceinline__ float hadd(v2f a) {
 // group: a reduce-scatter inside every group at once (the 8 groups of the wave reduce 8 different Gaussians' sums in the
 // same instructions).  Every level halves the number of live values while it sums over one more lane pairing:
 //   row_half_mirror (l <-> 7 - l), quad_perm [2,3,0,1] (l <-> l ^ 2), quad_perm [1,0,3,2] (l <-> l ^ 1):
-// a DPP add of each value with its partner lane, then a select by the lane bit: 21 instructions for 8 sums.
+// levels 2 and 3: two selects and a DPP add per pair of values; level 1: two bank-masked DPP adds (17 instructions for 8 sums).
 #define DPP_MOV_F32(x, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, 0xF, 0xF, false))
 #define DPP_ADD_F32(x, ctrl) ((x) + DPP_MOV_F32(x, ctrl))
 __device__ __forceinline__ float reduce_scatter8(float (&v)[8], int lane) {
-    // per pair of values (a, b) and partner lane p: this lane keeps one of the two sums and gives the other to its partner, so
-    // keep = mine(kept) + partner's(given) -- two selects (1.3 ns each) and ONE DPP add (1.8 ns) instead of two DPP adds and a select
-    const bool b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float keep = b2 ? v[i + 4] : v[i], give = b2 ? v[i] : v[i + 4];
-        v[i] = keep + DPP_MOV_F32(give, 0x141);                                             // row_half_mirror: l <-> 7 - l
+    const bool b1 = lane & 2, b0 = lane & 1;
+    // level 1 without selects: lane bit 2 is the parity of the lane's DPP bank (4 lanes), so two bank-masked DPP adds write the
+    // two halves of the result: banks 0, 2 (lanes 0-3 of every group) get v[i] + mirror(v[i]), banks 1, 3 get v[i+4] + mirror(v[i+4])
+    {
+        float t0, t1, t2, t3;
+        asm("s_nop 1\n"
+            "v_add_f32_dpp %0, %4, %4 row_half_mirror row_mask:0xf bank_mask:0x5\n"
+            "v_add_f32_dpp %1, %5, %5 row_half_mirror row_mask:0xf bank_mask:0x5\n"
+            "v_add_f32_dpp %2, %6, %6 row_half_mirror row_mask:0xf bank_mask:0x5\n"
+            "v_add_f32_dpp %3, %7, %7 row_half_mirror row_mask:0xf bank_mask:0x5\n"
+            "v_add_f32_dpp %0, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xa\n"
+            "v_add_f32_dpp %1, %9, %9 row_half_mirror row_mask:0xf bank_mask:0xa\n"
+            "v_add_f32_dpp %2, %10, %10 row_half_mirror row_mask:0xf bank_mask:0xa\n"
+            "v_add_f32_dpp %3, %11, %11 row_half_mirror row_mask:0xf bank_mask:0xa"
+            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+            : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]));
+        v[0] = t0; v[1] = t1; v[2] = t2; v[3] = t3;
     }
+    // levels 2, 3: per pair of values (a, b) and partner lane p, this lane keeps one of the two sums and gives the other to its
+    // partner: keep = mine(kept) + partner's(given) -- two selects (1.3 ns each) and ONE DPP add (1.8 ns)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const float keep = b1 ? v[i + 2] : v[i], give = b1 ? v[i] : v[i + 2];
@@ -1791,27 +1883,24 @@ int gsplat_bin(int64_t n, int64_t pair_capacity, const gsplat_view* v, const voi
     hipLaunchKernelGGL(split_count_kernel, dim3((unsigned)n_chunks(n_binned)), dim3(256), 0, st, (int)nb, ps.bin_start, sc.bvals,
                        (uint32_t)n_binned, ps.counts, ps.list_count, sc.seg_off);
     LAUNCH_CHECK("split_count_kernel");
-    hipLaunchKernelGGL(split_scatter_kernel, dim3((unsigned)n_chunks(n_binned)), dim3(256), 0, st, (int)nl, (int)nb, ps.bin_start, sc.bvals,
-                       (uint32_t)n_binned, ps.counts, ps.list_count, sc.seg_off, ps.ranges, sc.vals);
+    hipLaunchKernelGGL(split_scatter_kernel, dim3((unsigned)n_chunks(n_binned) + 1u), dim3(SS_THREADS), 0, st, (int)nl, (int)nb, ps.bin_start, sc.bvals,
+                       (uint32_t)n_binned, ps.counts, ps.list_count, sc.seg_off, ps.ranges, sc.vals, ps.order, ps.class_bounds);
     LAUNCH_CHECK("split_scatter_kernel");
-    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(1024), 0, st, (int)nl, ps.ranges, ps.order, ps.class_bounds);
-    LAUNCH_CHECK("plan_kernel");
     // F9 + F12: per-list sort by (depth, index); one launch per size class, grids bounded by what the class can hold
     uint64_t* vals = sc.vals;
     const auto cap = [&](int64_t min_len) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(nl, n_binned / min_len)); };
     if (n_binned >= 1024) {       // lists of 1024+ entries: 100 KB of LDS per workgroup; 8192+ fall back to global memory inside
-        hipLaunchKernelGGL((list_sort_kernel<512, 16, 13>), dim3(std::min(cap(1024), 256u)), dim3(512), 0, st, ps.order, ps.class_bounds, 0, ps.ranges,
+        hipLaunchKernelGGL((list_sort_kernel<512, 16, 13>), dim3(std::min(cap(1024), 256u)), dim3(512), 0, st, ps.order, ps.class_bounds, ps.ranges,
                            vals, sorted_ids);
         LAUNCH_CHECK("list_sort_kernel<8192>");
     }
-    if (n_binned >= 256) {
-        hipLaunchKernelGGL((list_sort_kernel<256, 4, 11>), dim3(std::min(cap(256), 4096u)), dim3(256), 0, st, ps.order, ps.class_bounds, 1, ps.ranges,
-                           vals, sorted_ids);
-        LAUNCH_CHECK("list_sort_kernel<1024>");
+    {
+        const unsigned mid_blocks = n_binned >= 256 ? std::min(cap(256), 4096u) : 0u;
+        const unsigned small_blocks = std::min((cap(1) + 3u) / 4u, 16384u);
+        hipLaunchKernelGGL(list_sort_small_kernel, dim3(mid_blocks + small_blocks), dim3(256), 0, st, ps.order, ps.class_bounds, mid_blocks,
+                           ps.ranges, vals, sorted_ids);
+        LAUNCH_CHECK("list_sort_small_kernel");
     }
-    hipLaunchKernelGGL((list_sort_kernel<64, 4, 9>), dim3(std::min(cap(1), 65536u)), dim3(64), 0, st, ps.order, ps.class_bounds, 2, ps.ranges, vals,
-                       sorted_ids);
-    LAUNCH_CHECK("list_sort_kernel<256>");
     return GSPLAT_OK;
 }
 

@@ -21,6 +21,9 @@ def short(name):
     name = name.replace("(anonymous namespace)::", "")
     m = re.match(r"(?:void )?([A-Za-z0-9_:]+)", name)
     base = m.group(1) if m else name
+    t = re.match(r"(?:void )?[A-Za-z0-9_:]+(<[0-9a-z, ]+>)\(", name)       # keep simple template arguments: list_sort_kernel<512, 16, 13>
+    if t:
+        base += t.group(1).replace(", ", ";").replace(",", ";")
     if "rocprim" in name:
         k = re.search(r"(radix_sort\w*|onesweep\w*|scan\w*|lookback\w*|histogram\w*|block_sort\w*|merge\w*)", name)
         base = "rocprim::" + (k.group(1) if k else "kernel")
