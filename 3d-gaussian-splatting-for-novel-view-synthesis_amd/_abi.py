@@ -14,9 +14,11 @@ GSPLAT_OK = 0
 GSPLAT_SCENE_OK = 0
 GSPLAT_SCENE_ALL_CULLED = 10
 GSPLAT_SCENE_ALL_OFFSCREEN = 11
-ABI_VERSION = 3
+ABI_VERSION = 4
 GSPLAT_PROJECT_COLOUR_FUSED = 1
 GSPLAT_PROJECT_COUNTS_MAPPED = 2
+GSPLAT_PROJECT_SAVE_SH_JACOBIAN = 4
+GSPLAT_BACKWARD_SH_JACOBIAN = 1
 
 _F = C.POINTER(C.c_float)
 
@@ -62,7 +64,7 @@ SIGNATURES = {
     "gsplat_rasterize_forward": (_INT, [_I64, _I64, _PV, _VP, _VP, _VP, _VP, _VP, _VP]),
     "gsplat_rasterize_backward_scratch_bytes": (_I64, [_I64, _I64]),
     "gsplat_rasterize_backward": (_INT, [_I64, _I64, _PV, _VP, _VP, _VP, _VP, _VP, C.c_int32, _VP, _I64, _VP]),
-    "gsplat_project_backward": (_INT, [_PG, _VP, _PV, _VP, _VP, _PGG, _VP]),
+    "gsplat_project_backward": (_INT, [_PG, _VP, _PV, _VP, _VP, _PGG, C.c_int32, _VP]),
     "gsplat_logit_grad": (_INT, [_I64, _PV, _VP, _VP, _VP, _VP]),
     "gsplat_sh_accumulate": (_INT, [_I64, C.c_int32, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP]),
     "gsplat_build_sigma": (_INT, [_I64, _VP, _VP, _VP, _VP]),

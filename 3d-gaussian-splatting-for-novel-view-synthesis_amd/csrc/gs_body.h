@@ -101,8 +101,10 @@ GS_HD Proj project_geometry(const GaussIn& in, bool fused, const Camera& cam, co
 
 // K1 core, part 2: colour of a visible Gaussian (SH when fused) and the record.
 // with_colour = false (fused inputs only): the SH colour is filled in later by colour_kernel; rgb = 0 here.
+// kj (nullable, fused inputs with colour): receives the 12 values sh_colour_jac leaves for the backward.
 template <class Coef>
-GS_HD RecOut project_finish(const GaussIn& in, const Proj& o, bool fused, Coef coef, const Camera& cam, bool with_colour = true) {
+GS_HD RecOut project_finish(const GaussIn& in, const Proj& o, bool fused, Coef coef, const Camera& cam, bool with_colour = true,
+                            float* kj = nullptr) {
     RecOut r;
     r.vis = o.vis;
     r.tiles = 0;
@@ -117,7 +119,8 @@ GS_HD RecOut project_finish(const GaussIn& in, const Proj& o, bool fused, Coef c
             if (with_colour) {
                 ShMid sm;
                 sh_basis(in.p, cam.eye, sm);
-                sh_colour(sm, coef, rgb);
+                if (kj) sh_colour_jac(sm, coef, rgb, kj);
+                else sh_colour(sm, coef, rgb);
             }
         } else {
             rgb[0] = in.col[0]; rgb[1] = in.col[1]; rgb[2] = in.col[2];
@@ -149,9 +152,10 @@ GS_HD RecOut project_core(const GaussIn& in, bool fused, Coef coef, const Camera
 // over the pixels of a = dL/d alpha * g.  dL/d opacity = M0, and dL/dq = -0.5 o a (alpha = o exp(-q/2)): with
 // q = A11 du^2 + 2 A12 du dv + A22 dv^2 and du = px - u:  d u = o (A11 Mx + A12 My), d v = o (A12 Mx + A22 My),
 // d A11 = -0.5 o Mxx, d A12 = -o Mxy, d A22 = -0.5 o Myy.  moments = false: r9[0..5] are those gradients themselves.
+// kj (nullable): the 12 values the forward saved with sh_colour_jac; then `coef` is not read.
 template <class Coef, class Emit>
 GS_HD GradOut project_backward_core(const GaussIn& in, bool fused, Coef coef, Emit emit_sh, const Camera& cam, const ViewK& vk,
-                                    bool vis, const float r9[9], bool moments = false) {
+                                    bool vis, const float r9[9], bool moments = false, const float* kj = nullptr) {
     GradOut g;
     for (int k = 0; k < 3; ++k) { g.p[k] = 0.f; g.sr[k] = 0.f; g.col[k] = 0.f; }
     for (int k = 0; k < 4; ++k) g.qr[k] = 0.f;
@@ -178,10 +182,14 @@ GS_HD GradOut project_backward_core(const GaussIn& in, bool fused, Coef coef, Em
             cov_from_params_backward(in.qr, cm, g.S9, g.sr, g.qr);
             ShMid sm;
             sh_basis(in.p, cam.eye, sm);
-            float rgb[3];
-            sh_colour(sm, coef, rgb);
             float gps[3];
-            sh_colour_backward(sm, coef, rgb, g.col, emit_sh, gps);
+            if (kj) {
+                sh_colour_backward_jac(sm, kj, g.col, emit_sh, gps);
+            } else {
+                float rgb[3];
+                sh_colour(sm, coef, rgb);
+                sh_colour_backward(sm, coef, rgb, g.col, emit_sh, gps);
+            }
             g.p[0] += gps[0]; g.p[1] += gps[1]; g.p[2] += gps[2];
         }
     } else if (fused) {

@@ -144,7 +144,18 @@ struct ShMid {
     float Y[16];
 };
 
+// The colour of a Gaussian must not depend on WHICH kernel evaluates it (projection kernel, colour pass, with or without the
+// saved Jacobian: the compiler fuses a * b + c into an fma or not depending on the surrounding code), or a render under
+// no_grad would differ from the same render with gradients in the last bit.  So contraction is switched off in the functions
+// the colour goes through, and the one fma that matters for speed is written out.
+#if defined(__clang__)
+#define GS_NO_CONTRACT _Pragma("clang fp contract(off)")
+#else
+#define GS_NO_CONTRACT
+#endif
+
 GS_HD void sh_basis(const float p[3], const float eye[3], ShMid& m) {
+    GS_NO_CONTRACT
     m.v[0] = p[0] - eye[0]; m.v[1] = p[1] - eye[1]; m.v[2] = p[2] - eye[2];
     m.n = sqrtf(m.v[0] * m.v[0] + m.v[1] * m.v[1] + m.v[2] * m.v[2]);
     const float inv = 1.0f / (m.n + 1e-8f);
@@ -164,11 +175,36 @@ GS_HD void sh_basis(const float p[3], const float eye[3], ShMid& m) {
 // coef(k, ch) returns the SH coefficient of basis k, channel ch.
 template <class Coef>
 GS_HD void sh_colour(const ShMid& m, Coef coef, float rgb[3]) {
+    GS_NO_CONTRACT
     for (int ch = 0; ch < 3; ++ch) {
         float acc = 0.f;
-        for (int k = 0; k < 16; ++k) acc += coef(k, ch) * m.Y[k];
+        for (int k = 0; k < 16; ++k) acc = fmaf(coef(k, ch), m.Y[k], acc);
         rgb[ch] = sigmoidf_(acc);
     }
+}
+
+// dd[m] = sum_k dY[k] * d Y_k / d d_m: the basis gradient w.r.t. the unit direction, contracted with dY.
+GS_HD void sh_basis_grad(const ShMid& m, const float dY[16], float dd[3]) {
+    const float x = m.d[0], y = m.d[1], z = m.d[2];
+    const float xx = x * x, yy = y * y, zz = z * z;
+    dd[0] = -GS_K1 * dY[3] + GS_K2A * y * dY[4] + GS_K2A * z * dY[7] + 2.f * GS_K2C * x * dY[8] + 6.f * GS_K3A * x * y * dY[9] +
+            GS_K3B * y * z * dY[10] - 2.f * GS_K3C * x * y * dY[11] - 6.f * GS_K3D * x * z * dY[12] +
+            GS_K3C * (4.f * zz - 3.f * xx - yy) * dY[13] + 2.f * GS_K3E * x * z * dY[14] + GS_K3A * (3.f * xx - 3.f * yy) * dY[15];
+    dd[1] = -GS_K1 * dY[1] + GS_K2A * x * dY[4] + GS_K2A * z * dY[5] - 2.f * GS_K2C * y * dY[8] +
+            GS_K3A * (3.f * xx - 3.f * yy) * dY[9] + GS_K3B * x * z * dY[10] + GS_K3C * (4.f * zz - xx - 3.f * yy) * dY[11] -
+            6.f * GS_K3D * y * z * dY[12] - 2.f * GS_K3C * x * y * dY[13] - 2.f * GS_K3E * y * z * dY[14] -
+            6.f * GS_K3A * x * y * dY[15];
+    dd[2] = GS_K1 * dY[2] + GS_K2A * y * dY[5] + 6.f * GS_K2B * z * dY[6] + GS_K2A * x * dY[7] + GS_K3B * x * y * dY[10] +
+            8.f * GS_K3C * y * z * dY[11] + GS_K3D * (6.f * zz - 3.f * xx - 3.f * yy) * dY[12] + 8.f * GS_K3C * x * z * dY[13] +
+            GS_K3E * (xx - yy) * dY[14];
+}
+
+// d = v / (n + eps), v = p - eye: gradient w.r.t. the direction -> gradient w.r.t. the point.
+GS_HD void sh_dir_to_point(const ShMid& m, const float dd[3], float g_p[3]) {
+    const float ne = m.n + 1e-8f;
+    const float dot = dd[0] * m.v[0] + dd[1] * m.v[1] + dd[2] * m.v[2];
+    const float c = (m.n > 0.f) ? dot / (m.n * ne * ne) : 0.f;
+    for (int k = 0; k < 3; ++k) g_p[k] = dd[k] / ne - m.v[k] * c;
 }
 
 // B3 (colour part).  g_rgb = dL/d colour.  Emits dL/dcoef through `emit(k, ch, value)`; returns dL/dp in g_p.
@@ -184,24 +220,35 @@ GS_HD void sh_colour_backward(const ShMid& m, Coef coef, const float rgb[3], con
             dY[k] += dpre * cf;
         }
     }
-    const float x = m.d[0], y = m.d[1], z = m.d[2];
-    const float xx = x * x, yy = y * y, zz = z * z;
     float dd[3];
-    dd[0] = -GS_K1 * dY[3] + GS_K2A * y * dY[4] + GS_K2A * z * dY[7] + 2.f * GS_K2C * x * dY[8] + 6.f * GS_K3A * x * y * dY[9] +
-            GS_K3B * y * z * dY[10] - 2.f * GS_K3C * x * y * dY[11] - 6.f * GS_K3D * x * z * dY[12] +
-            GS_K3C * (4.f * zz - 3.f * xx - yy) * dY[13] + 2.f * GS_K3E * x * z * dY[14] + GS_K3A * (3.f * xx - 3.f * yy) * dY[15];
-    dd[1] = -GS_K1 * dY[1] + GS_K2A * x * dY[4] + GS_K2A * z * dY[5] - 2.f * GS_K2C * y * dY[8] +
-            GS_K3A * (3.f * xx - 3.f * yy) * dY[9] + GS_K3B * x * z * dY[10] + GS_K3C * (4.f * zz - xx - 3.f * yy) * dY[11] -
-            6.f * GS_K3D * y * z * dY[12] - 2.f * GS_K3C * x * y * dY[13] - 2.f * GS_K3E * y * z * dY[14] -
-            6.f * GS_K3A * x * y * dY[15];
-    dd[2] = GS_K1 * dY[2] + GS_K2A * y * dY[5] + 6.f * GS_K2B * z * dY[6] + GS_K2A * x * dY[7] + GS_K3B * x * y * dY[10] +
-            8.f * GS_K3C * y * z * dY[11] + GS_K3D * (6.f * zz - 3.f * xx - 3.f * yy) * dY[12] + 8.f * GS_K3C * x * z * dY[13] +
-            GS_K3E * (xx - yy) * dY[14];
-    // d = v / (n + eps)
-    const float ne = m.n + 1e-8f;
-    const float dot = dd[0] * m.v[0] + dd[1] * m.v[1] + dd[2] * m.v[2];
-    const float c = (m.n > 0.f) ? dot / (m.n * ne * ne) : 0.f;
-    for (int k = 0; k < 3; ++k) g_p[k] = dd[k] / ne - m.v[k] * c;
+    sh_basis_grad(m, dY, dd);
+    sh_dir_to_point(m, dd, g_p);
+}
+
+// F3 together with what its backward needs, so that the backward does not have to read the 48 coefficients again (192 of
+// the 236 input bytes of a Gaussian):  KJ[ch] = d rgb_ch / d logit_ch,  KJ[3 + 3 ch + m] = d logit_ch / d p_m.
+template <class Coef>
+GS_HD void sh_colour_jac(const ShMid& m, Coef coef, float rgb[3], float KJ[12]) {
+    sh_colour(m, coef, rgb);                                 // (the same instructions as without the Jacobian: see sh_basis)
+    for (int ch = 0; ch < 3; ++ch) {
+        float cf[16];
+        for (int k = 0; k < 16; ++k) cf[k] = coef(k, ch);
+        KJ[ch] = rgb[ch] * (1.f - rgb[ch]);
+        float dd[3];
+        sh_basis_grad(m, cf, dd);
+        sh_dir_to_point(m, dd, KJ + 3 + 3 * ch);
+    }
+}
+
+// B3 from the saved KJ: dL/dcoef(k, ch) = dpre_ch Y_k, dL/dp = sum_ch dpre_ch (d logit_ch / d p).
+template <class Emit>
+GS_HD void sh_colour_backward_jac(const ShMid& m, const float KJ[12], const float g_rgb[3], Emit emit, float g_p[3]) {
+    g_p[0] = g_p[1] = g_p[2] = 0.f;
+    for (int ch = 0; ch < 3; ++ch) {
+        const float dpre = g_rgb[ch] * KJ[ch];
+        for (int k = 0; k < 16; ++k) emit(k, ch, dpre * m.Y[k]);
+        for (int mm = 0; mm < 3; ++mm) g_p[mm] += dpre * KJ[3 + 3 * ch + mm];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

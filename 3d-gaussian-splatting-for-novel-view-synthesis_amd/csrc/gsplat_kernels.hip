@@ -99,6 +99,7 @@ struct ProjectState {
     uint2* ranges;           // [lists] start, end in the pair arrays
     uint32_t* order;         // [lists] launch order: longest list first
     uint32_t* class_bounds;  // [8] boundaries of the sort size classes inside `order`
+    float* kj;               // [n][12] fused inputs, GSPLAT_PROJECT_SAVE_SH_JACOBIAN: d rgb / d logit (3), d logit / d position (9)
     int64_t bytes;
 };
 
@@ -125,6 +126,7 @@ ProjectState carve_project(void* base, int64_t n, int64_t nl) {
     s.ranges = (uint2*)(p + o); o += up(nl * 8);
     s.order = (uint32_t*)(p + o); o += up(nl * 4);
     s.class_bounds = (uint32_t*)(p + o); o += up(8 * 4);
+    s.kj = (float*)(p + o); o += up(n * 48);
     s.bytes = o;
     return s;
 }
@@ -314,10 +316,11 @@ __device__ __forceinline__ void for_each_list(u2 rect, uint32_t nt, uint32_t mas
 // bin_count_kernel accumulates into.  Epilogue: per-wave counts -> sharded counters -> the LAST wave to arrive (agent-scope
 // acq_rel counter) adds the shards up, writes the totals (device, and the caller's mapped host block if given) and leaves
 // the counter block zeroed for the next call.
-template <bool FUSED, bool COLOUR>
+// JAC (FUSED && COLOUR only): also store, per visible Gaussian, the 12 values that spare the backward the SH coefficients.
+template <bool FUSED, bool COLOUR, bool JAC = false>
 __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const float* __restrict__ c2w, Camera* __restrict__ cam_out, ViewK vk,
                                                      Records out, CounterBlock* cb, DevCounts* counts, DevCounts* counts_mapped,
-                                                     uint32_t* __restrict__ bin_total, int nb) {
+                                                     uint32_t* __restrict__ bin_total, int nb, float* __restrict__ kj_out) {
     __shared__ ProjectLds s;
     __shared__ float s_dc[FUSED && COLOUR ? 64 * 3 : 4];
     __shared__ float s_rest[FUSED && COLOUR ? 64 * 45 : 4];
@@ -347,8 +350,9 @@ __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const f
     }
     RecOut r;
     r.vis = o.vis; r.tiles = 0; r.mask = 0u; r.ref_tiles = 0; r.rect = u2{0u, 0u}; r.ref_rect = u2{0u, 0u};
+    float kj[12];
     if (FUSED) {
-        if (o.vis == VIS_OK) r = project_finish(in, o, true, ShCoefLds{s_dc + lane * 3, s_rest + lane * 45}, cam, COLOUR);
+        if (o.vis == VIS_OK) r = project_finish(in, o, true, ShCoefLds{s_dc + lane * 3, s_rest + lane * 45}, cam, COLOUR, JAC ? kj : nullptr);
     } else if (o.vis == VIS_OK) {
         r = project_finish(in, o, false, ShCoefLds{nullptr, nullptr}, cam);
     }
@@ -360,6 +364,12 @@ __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const f
             out.rect[i] = r.rect;
             out.depth[i] = r.r2.w;
             out.mask[i] = r.mask;
+            if (JAC) {                           // 48 contiguous bytes per lane
+                f4* dst = reinterpret_cast<f4*>(kj_out + i * 12);
+                dst[0] = f4{kj[0], kj[1], kj[2], kj[3]};
+                dst[1] = f4{kj[4], kj[5], kj[6], kj[7]};
+                dst[2] = f4{kj[8], kj[9], kj[10], kj[11]};
+            }
         }
         out.tiles[i] = r.tiles;
     }
@@ -429,8 +439,9 @@ __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const f
 // ---- K1b: SH colour (fused inputs) -------------------------------------------------------------------
 // F3 for the Gaussians that were binned: 192 of the 236 input bytes per Gaussian are SH coefficients.  Writes r, g, b into
 // the record line the geometry pass left (z stays).
+template <bool JAC>
 __global__ __launch_bounds__(64) void colour_kernel(gsplat_gaussians g, const Camera* __restrict__ camp, const uint32_t* __restrict__ tiles,
-                                                    Rec64* __restrict__ rec) {
+                                                    Rec64* __restrict__ rec, float* __restrict__ kj_out) {
     __shared__ float s_pos[64 * 3], s_dc[64 * 3], s_rest[64 * 45];
     const int lane = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * 64, i = row0 + lane;
@@ -446,7 +457,16 @@ __global__ __launch_bounds__(64) void colour_kernel(gsplat_gaussians g, const Ca
         ShMid sm;
         sh_basis(p, cam.eye, sm);
         float rgb[3];
-        sh_colour(sm, ShCoefLds{s_dc + lane * 3, s_rest + lane * 45}, rgb);
+        if (JAC) {
+            float kj[12];
+            sh_colour_jac(sm, ShCoefLds{s_dc + lane * 3, s_rest + lane * 45}, rgb, kj);
+            f4* dst = reinterpret_cast<f4*>(kj_out + i * 12);
+            dst[0] = f4{kj[0], kj[1], kj[2], kj[3]};
+            dst[1] = f4{kj[4], kj[5], kj[6], kj[7]};
+            dst[2] = f4{kj[8], kj[9], kj[10], kj[11]};
+        } else {
+            sh_colour(sm, ShCoefLds{s_dc + lane * 3, s_rest + lane * 45}, rgb);
+        }
         float* r2 = reinterpret_cast<float*>(&rec[i].r2);
         r2[0] = rgb[0]; r2[1] = rgb[1]; r2[2] = rgb[2];
     }
@@ -1565,10 +1585,12 @@ struct ShEmitLds {
     }
 };
 
-template <bool FUSED>
+// JAC (fused inputs): the forward left d rgb / d logit and d logit / d position in project_state (GSPLAT_PROJECT_SAVE_SH_JACOBIAN),
+// so the 192 bytes of SH coefficients are not read again: 48 instead of 192 bytes per visible Gaussian, and no dY accumulators.
+template <bool FUSED, bool JAC = false>
 __global__ __launch_bounds__(64) void project_backward_kernel(gsplat_gaussians g, const Camera* __restrict__ camp, ViewK vk,
                                                               const uint32_t* __restrict__ tiles, const float* __restrict__ grad2d,
-                                                              gsplat_gaussian_grads out, bool factored) {
+                                                              gsplat_gaussian_grads out, bool factored, const float* __restrict__ kj_in) {
     __shared__ ProjectLds s;
     __shared__ float s_dc[FUSED ? 64 * 3 : 4];
     __shared__ float s_rest[FUSED ? 64 * 45 : 4];
@@ -1578,11 +1600,18 @@ __global__ __launch_bounds__(64) void project_backward_kernel(gsplat_gaussians g
     const bool vis = (i < g.n) && tiles[i] != 0;
     const bool any_vis = __any(vis);
     float r9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float kj[12];
     if (any_vis) {
         stage_geometry<FUSED>(s, g, row0, lane);
-        if (FUSED) {
+        if (FUSED && !JAC) {
             stage_rows<3>(s_dc, g.f_dc, row0, g.n, lane);
             stage_rows<45>(s_rest, g.f_rest, row0, g.n, lane);
+        }
+        if (JAC && vis) {
+            const f4* src = reinterpret_cast<const f4*>(kj_in + i * 12);
+            const f4 k0 = src[0], k1 = src[1], k2 = src[2];
+            kj[0] = k0.x; kj[1] = k0.y; kj[2] = k0.z; kj[3] = k0.w; kj[4] = k1.x; kj[5] = k1.y; kj[6] = k1.z; kj[7] = k1.w;
+            kj[8] = k2.x; kj[9] = k2.y; kj[10] = k2.z; kj[11] = k2.w;
         }
         if (vis) {
             const f4 g0 = *reinterpret_cast<const f4*>(grad2d + i * 16), g1 = *reinterpret_cast<const f4*>(grad2d + i * 16 + 4);
@@ -1595,7 +1624,7 @@ __global__ __launch_bounds__(64) void project_backward_kernel(gsplat_gaussians g
     if (vis) {
         const GaussIn in = gauss_from_lds<FUSED>(s, lane);
         go = project_backward_core(in, FUSED, ShCoefLds{s_dc + lane * 3, s_rest + lane * 45},
-                                   ShEmitLds{s_dc + lane * 3, s_rest + lane * 45}, cam, vk, true, r9, true);
+                                   ShEmitLds{s_dc + lane * 3, s_rest + lane * 45}, cam, vk, true, r9, true, JAC ? kj : nullptr);
     } else {
 #pragma unroll
         for (int k = 0; k < 3; ++k) { go.p[k] = 0.f; go.sr[k] = 0.f; go.col[k] = 0.f; }
@@ -1826,17 +1855,20 @@ int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_vie
     const ViewK vk = make_viewk(*v);
     const bool mapped = (flags & GSPLAT_PROJECT_COUNTS_MAPPED) != 0;
     const bool colour_inside = !fused || (flags & GSPLAT_PROJECT_COLOUR_FUSED) != 0;
+    const bool jac = fused && (flags & GSPLAT_PROJECT_SAVE_SH_JACOBIAN) != 0;
     if (n > 0) {
         Records out{ps.rec, ps.rect, ps.depth, ps.tiles, ps.mask, nullptr, nullptr};
         DevCounts* cm = mapped ? (DevCounts*)counts_host : nullptr;
         CounterBlock* cb = (CounterBlock*)scratch;
         const dim3 grid(blocks64(n)), block(64);
         if (!fused)
-            hipLaunchKernelGGL((project_kernel<false, true>), grid, block, 0, st, *g, c2w, ps.cam, vk, out, cb, ps.counts, cm, ps.bin_total, (int)nb);
+            hipLaunchKernelGGL((project_kernel<false, true>), grid, block, 0, st, *g, c2w, ps.cam, vk, out, cb, ps.counts, cm, ps.bin_total, (int)nb, nullptr);
+        else if (colour_inside && jac)
+            hipLaunchKernelGGL((project_kernel<true, true, true>), grid, block, 0, st, *g, c2w, ps.cam, vk, out, cb, ps.counts, cm, ps.bin_total, (int)nb, ps.kj);
         else if (colour_inside)
-            hipLaunchKernelGGL((project_kernel<true, true>), grid, block, 0, st, *g, c2w, ps.cam, vk, out, cb, ps.counts, cm, ps.bin_total, (int)nb);
+            hipLaunchKernelGGL((project_kernel<true, true>), grid, block, 0, st, *g, c2w, ps.cam, vk, out, cb, ps.counts, cm, ps.bin_total, (int)nb, nullptr);
         else
-            hipLaunchKernelGGL((project_kernel<true, false>), grid, block, 0, st, *g, c2w, ps.cam, vk, out, cb, ps.counts, cm, ps.bin_total, (int)nb);
+            hipLaunchKernelGGL((project_kernel<true, false>), grid, block, 0, st, *g, c2w, ps.cam, vk, out, cb, ps.counts, cm, ps.bin_total, (int)nb, nullptr);
         LAUNCH_CHECK("project_kernel");
         if (counts_host && !mapped) HIP_TRY(hipMemcpyAsync(counts_host, ps.counts, sizeof(gsplat_counts), hipMemcpyDeviceToHost, st));
     } else {                        // no kernel runs: the counters are zero by definition
@@ -1850,7 +1882,8 @@ int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_vie
                            ps.bin_total, ps.block_off, ps.list_count, ps.ranges, (int)nl);
         LAUNCH_CHECK("bin_count_kernel");
         if (!colour_inside) {
-            hipLaunchKernelGGL(colour_kernel, dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, ps.tiles, ps.rec);
+            if (jac) hipLaunchKernelGGL(colour_kernel<true>, dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, ps.tiles, ps.rec, ps.kj);
+            else hipLaunchKernelGGL(colour_kernel<false>, dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, ps.tiles, ps.rec, nullptr);
             LAUNCH_CHECK("colour_kernel");
         }
     }
@@ -1979,7 +2012,7 @@ int gsplat_rasterize_backward(int64_t n, int64_t n_binned, const gsplat_view* v,
 }
 
 int gsplat_project_backward(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, const void* project_state,
-                            const float* grad2d, const gsplat_gaussian_grads* out, void* stream_) {
+                            const float* grad2d, const gsplat_gaussian_grads* out, int32_t flags, void* stream_) {
     bool fused = false;
     int rc = check_gaussians(g, &fused);
     if (rc) return rc;
@@ -1995,10 +2028,12 @@ int gsplat_project_backward(const gsplat_gaussians* g, const float* c2w, const g
     hipStream_t st = (hipStream_t)stream_;
     ProjectState ps = carve_project((void*)project_state, g->n, n_lists(v));
     const ViewK vk = make_viewk(*v);
-    if (fused)
-        hipLaunchKernelGGL(project_backward_kernel<true>, dim3(blocks64(g->n)), dim3(64), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out, factored);
+    if (fused && (flags & GSPLAT_BACKWARD_SH_JACOBIAN))
+        hipLaunchKernelGGL((project_backward_kernel<true, true>), dim3(blocks64(g->n)), dim3(64), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out, factored, ps.kj);
+    else if (fused)
+        hipLaunchKernelGGL((project_backward_kernel<true, false>), dim3(blocks64(g->n)), dim3(64), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out, factored, nullptr);
     else
-        hipLaunchKernelGGL(project_backward_kernel<false>, dim3(blocks64(g->n)), dim3(64), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out, false);
+        hipLaunchKernelGGL((project_backward_kernel<false, false>), dim3(blocks64(g->n)), dim3(64), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out, false, nullptr);
     LAUNCH_CHECK("project_backward_kernel");
     return GSPLAT_OK;
 }

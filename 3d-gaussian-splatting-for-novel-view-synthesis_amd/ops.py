@@ -257,9 +257,12 @@ def _make_gaussians(n, pos, opacity_raw, color=None, sigma=None, scale_raw=None,
     return _abi.Gaussians(n, _p(pos), _p(opacity_raw), _p(color), _p(sigma), _p(scale_raw), _p(q_raw), _p(f_dc), _p(f_rest))
 
 
+_sh_jacobian = True      # tests / ablations switch it off: the backward then reads the SH coefficients again (same gradients)
+
+
 class _Frame:
     """Everything the backward pass needs from one forward call."""
-    __slots__ = ("view", "n", "n_pairs", "proj_state", "bin_state", "accum", "fused", "inputs", "c2w", "empty", "grad2d")
+    __slots__ = ("view", "n", "n_pairs", "proj_state", "bin_state", "accum", "fused", "inputs", "c2w", "empty", "grad2d", "sh_jacobian")
 
 
 class _Pending:
@@ -267,7 +270,7 @@ class _Pending:
     __slots__ = ("frame", "gaussians", "pinned", "ready", "device", "stream", "capacity")
 
 
-def _forward_begin(fused, view, c2w, pos, opacity_raw, a, b, c, d):
+def _forward_begin(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad=False):
     """First half of the forward pass: everything up to (not including) the host's wait for the counters.  Returns
     (pending, None), or (None, result) when there is nothing to wait for (zero Gaussians).  Inside a deferred_checks()
     block (and once a pair capacity is known for the device) the second half will not wait: pending.capacity is set."""
@@ -284,7 +287,7 @@ def _forward_begin(fused, view, c2w, pos, opacity_raw, a, b, c, d):
         ins = dict(color=_f32(a, (n, 3), "color"), sigma=_f32(b, (n, 3, 3), "sigma"))
     g = _make_gaussians(n, pos32, opa32, **ins)
     fr = _Frame()
-    fr.view, fr.n, fr.fused, fr.c2w, fr.empty = view, n, fused, c2w32, False
+    fr.view, fr.n, fr.fused, fr.c2w, fr.empty, fr.sh_jacobian = view, n, fused, c2w32, False, False
     fr.inputs = dict(pos=pos32, opacity_raw=opa32, **ins)
     if n == 0:      # nothing survives by construction: the reference returns the zero image (render.py:109-112)
         fr.empty, fr.proj_state = True, None
@@ -302,6 +305,10 @@ def _forward_begin(fused, view, c2w, pos, opacity_raw, a, b, c, d):
         # the counters go straight into the pinned block (mapped into the device's address space: no copy operation);
         # a frame that will not wait for them evaluates the SH colour inside the projection kernel
         flags = _abi.GSPLAT_PROJECT_COUNTS_MAPPED | (_abi.GSPLAT_PROJECT_COLOUR_FUSED if deferred else 0)
+        # a backward pass will follow: the colour pass leaves 48 bytes per Gaussian that spare it the 192 bytes of SH coefficients
+        fr.sh_jacobian = bool(fused and need_grad and _sh_jacobian)
+        if fr.sh_jacobian:
+            flags |= _abi.GSPLAT_PROJECT_SAVE_SH_JACOBIAN
         with _stage("project"):
             _abi.check(lib.gsplat_project(C.byref(g), _p(c2w32), C.byref(view), _p(fr.proj_state), _p(counters),
                                           counters.numel(), C.c_void_p(pend.pinned.data_ptr()), C.c_void_p(pend.ready.cuda_event),
@@ -359,7 +366,7 @@ def _forward_end(pend, need_grad):
 
 
 def _forward_impl(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad):
-    pend, done = _forward_begin(fused, view, c2w, pos, opacity_raw, a, b, c, d)
+    pend, done = _forward_begin(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad)
     return done if pend is None else _forward_end(pend, need_grad)
 
 
@@ -434,7 +441,8 @@ def _backward_impl(fr, grad_image):
                                 _p(out.get("scale_raw")), _p(out.get("q_raw")), _p(out.get("f_dc")), _p(out.get("f_rest")))
         with _stage("project_backward"):
             _abi.check(lib.gsplat_project_backward(C.byref(g), _p(fr.c2w), C.byref(fr.view), _p(fr.proj_state), _p(grad2d),
-                                                   C.byref(gg), st), "gsplat_project_backward")
+                                                   C.byref(gg), _abi.GSPLAT_BACKWARD_SH_JACOBIAN if fr.sh_jacobian else 0,
+                                                   st), "gsplat_project_backward")
     if factored:
         out["f_dc"] = out["f_rest"] = None
     return out

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GSPLAT_ABI_VERSION 3
+#define GSPLAT_ABI_VERSION 4
 
 /* call status */
 #define GSPLAT_OK 0
@@ -130,9 +130,14 @@ int64_t gsplat_bin_scratch_bytes(int64_t pair_capacity, const gsplat_view* v); /
  *                  waits for it (not for the stream: the first binning kernel and, without COLOUR_FUSED, the SH colour
  *                  pass are queued BEHIND the event and run during the host's round trip) and reads n_binned.
  *   flags          GSPLAT_PROJECT_COLOUR_FUSED: evaluate the SH colour inside the projection kernel (one pass over the
- *                  inputs: best when the host does NOT wait for the counters -- see gsplat_bin's pair_capacity).      */
+ *                  inputs: best when the host does NOT wait for the counters -- see gsplat_bin's pair_capacity).
+ *                  GSPLAT_PROJECT_SAVE_SH_JACOBIAN (fused inputs; set it when a backward pass will follow): the colour pass
+ *                  also leaves, per visible Gaussian, d colour / d logit and d logit / d position (48 bytes) in
+ *                  project_state, so that gsplat_project_backward (flag GSPLAT_BACKWARD_SH_JACOBIAN) does not read the
+ *                  192 bytes of SH coefficients again.  Ignored for un-fused inputs.                                   */
 #define GSPLAT_PROJECT_COLOUR_FUSED 1
 #define GSPLAT_PROJECT_COUNTS_MAPPED 2
+#define GSPLAT_PROJECT_SAVE_SH_JACOBIAN 4
 int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, void* project_state,
                    void* scratch, int64_t scratch_bytes, gsplat_counts* counts_host, void* counts_event, int32_t flags,
                    void* stream);
@@ -176,10 +181,14 @@ int gsplat_rasterize_backward(int64_t n, int64_t pair_capacity, const gsplat_vie
 /* B2 (+B3 when fused): chain the 2D gradients back to the inputs of gsplat_project.
  * Factored form (fused inputs; out->f_dc and out->f_rest NULL): instead of the 48 SH-coefficient
  * gradients per Gaussian, out->color[n,3] (if given) receives the gradient w.r.t. the colour LOGIT (the sigmoid's argument,
- * spherical_harmonics.py:166); gsplat_sh_accumulate turns logit gradients of any number of views into SH gradients.  */
+ * spherical_harmonics.py:166); gsplat_sh_accumulate turns logit gradients of any number of views into SH gradients.
+ *   flags          GSPLAT_BACKWARD_SH_JACOBIAN: project_state was filled by gsplat_project with
+ *                  GSPLAT_PROJECT_SAVE_SH_JACOBIAN for the SAME g and c2w (same results up to fp32 rounding, 144 bytes
+ *                  less HBM traffic per visible Gaussian).  Without the flag the SH coefficients are read again.         */
+#define GSPLAT_BACKWARD_SH_JACOBIAN 1
 int gsplat_project_backward(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v,
                             const void* project_state, const float* grad2d, const gsplat_gaussian_grads* out,
-                            void* stream);
+                            int32_t flags, void* stream);
 
 /* Data-parallel exchange helper: per view the SH-coefficient gradient is the outer product of the 3
  * colour-logit gradients with the 16 SH basis values of the view direction, so ranks exchange 12 B per Gaussian and view

@@ -529,6 +529,31 @@ def test_deterministic_backward_matches_the_goldens_and_repeats_bitwise(gs, name
         util.check_grad(p1[k].grad.cpu().numpy(), d["grad_" + k], k, cal=d["grad32_" + k])
 
 
+@pytest.mark.parametrize("name", ["g1_generic", "g2_ragged", "g6_huge"])
+def test_backward_from_the_saved_sh_jacobian_is_the_backward_from_the_coefficients(gs, name):
+    """A forward pass that will be differentiated leaves d colour / d logit and d logit / d position (48 B per Gaussian) in
+    project_state (GSPLAT_PROJECT_SAVE_SH_JACOBIAN), and the backward takes them instead of reading the 192 B of SH coefficients
+    again (GSPLAT_BACKWARD_SH_JACOBIAN).  Same gradients as the coefficient path up to fp32 rounding, both within the golden
+    tolerances; deterministic mode so that the two runs differ by nothing else."""
+    ops = _ops()
+    d = util.load(name)
+    old = gs.set_deterministic(True)
+    try:
+        assert ops._sh_jacobian
+        img_j, pj = _fused(gs, d)
+        ops._sh_jacobian = False
+        img_c, pc = _fused(gs, d)
+    finally:
+        ops._sh_jacobian = True
+        gs.set_deterministic(old)
+    assert float((img_j - img_c).abs().max()) <= 1e-6            # (two instantiations of the colour code: fp contraction may differ)
+    for k in util.PARAMS:
+        a, b = pj[k].grad, pc[k].grad
+        scale = float(b.abs().max()) + 1e-30
+        assert float((a - b).abs().max()) <= 2e-5 * scale, (k, float((a - b).abs().max()), scale)
+        util.check_grad(a.cpu().numpy(), d["grad_" + k], k, cal=d["grad32_" + k])
+
+
 def test_counters_arrive_by_copy_or_by_mapped_store(gs):
     """gsplat_project hands the counters to the host either with a copy operation (any host memory, flags = 0: what the
     INTEGRATION.md stub does) or by storing them itself into device-mapped pinned memory (GSPLAT_PROJECT_COUNTS_MAPPED); with
