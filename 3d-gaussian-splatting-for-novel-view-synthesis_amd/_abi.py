@@ -18,6 +18,7 @@ ABI_VERSION = 4
 GSPLAT_PROJECT_COLOUR_FUSED = 1
 GSPLAT_PROJECT_COUNTS_MAPPED = 2
 GSPLAT_PROJECT_SAVE_SH_JACOBIAN = 4
+GSPLAT_PROJECT_COUNTS_LATE = 8
 GSPLAT_BACKWARD_SH_JACOBIAN = 1
 
 _F = C.POINTER(C.c_float)

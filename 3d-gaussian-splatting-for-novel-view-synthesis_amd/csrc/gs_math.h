@@ -285,15 +285,15 @@ struct Proj {
 // rasterizer's own evaluation of q), so a "no" means alpha = 0 on every pixel of the rectangle.
 GS_HD bool ellipse_touches_rect(const Proj& o, float chi_pad, float r12_22, float r12_11, float x0, float y0, float x1, float y1) {
     const float dx0 = x0 - o.u, dx1 = x1 - o.u, dy0 = y0 - o.v, dy1 = y1 - o.v;
-    if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;
-    float best = 3.0e38f;
-    const float xs[2] = {dx0, dx1}, ys[2] = {dy0, dy1};
-    for (int k = 0; k < 2; ++k) {
-        const float X = xs[k], t = clampf_(r12_22 * X, dy0, dy1);             // minimiser of q along the edge x = X
-        best = fminf(best, o.A11 * X * X + (2.f * o.A12 * X + o.A22 * t) * t);
-        const float Y = ys[k], s_ = clampf_(r12_11 * Y, dx0, dx1);            // ... along the edge y = Y
-        best = fminf(best, o.A22 * Y * Y + (2.f * o.A12 * Y + o.A11 * s_) * s_);
-    }
+    const bool in_x = dx0 <= 0.f && dx1 >= 0.f, in_y = dy0 <= 0.f && dy1 >= 0.f;
+    if (in_x && in_y) return true;
+    // Only the edges that FACE the centre can hold the minimum (on an edge the centre is not beyond, q decreases towards the
+    // inside of the rectangle): at most one vertical and one horizontal edge, each a clamped 1-D quadratic (corners included).
+    const float X = dx0 > 0.f ? dx0 : dx1, t = clampf_(r12_22 * X, dy0, dy1);               // minimiser of q along the edge x = X
+    const float qx = o.A11 * X * X + (2.f * o.A12 * X + o.A22 * t) * t;
+    const float Y = dy0 > 0.f ? dy0 : dy1, s_ = clampf_(r12_11 * Y, dx0, dx1);              // ... along the edge y = Y
+    const float qy = o.A22 * Y * Y + (2.f * o.A12 * Y + o.A11 * s_) * s_;
+    const float best = fminf(in_x ? 3.0e38f : qx, in_y ? 3.0e38f : qy);
     return !(best > chi_pad);          // NaN -> true
 }
 

@@ -317,7 +317,10 @@ __device__ __forceinline__ void for_each_list(u2 rect, uint32_t nt, uint32_t mas
 // acq_rel counter) adds the shards up, writes the totals (device, and the caller's mapped host block if given) and leaves
 // the counter block zeroed for the next call.
 // JAC (FUSED && COLOUR only): also store, per visible Gaussian, the 12 values that spare the backward the SH coefficients.
-template <bool FUSED, bool COLOUR, bool JAC = false>
+// TOTALS = false (GSPLAT_PROJECT_COUNTS_LATE): the waves only add to the sharded counters and leave; bin_count_kernel, queued
+// right behind, totals and clears them.  (With the totals in here every wave waits for ALL its stores and atomics and then for
+// a returning arrival atomic before it can retire: a quarter of a wave's life.)
+template <bool FUSED, bool COLOUR, bool JAC = false, bool TOTALS = true>
 __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const float* __restrict__ c2w, Camera* __restrict__ cam_out, ViewK vk,
                                                      Records out, CounterBlock* cb, DevCounts* counts, DevCounts* counts_mapped,
                                                      uint32_t* __restrict__ bin_total, int nb, float* __restrict__ kj_out) {
@@ -392,14 +395,16 @@ __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const f
         // The adds above are agent-scope atomics (performed at the memory side, coherent without any cache maintenance); they
         // only have to be COMPLETE before this wave reports in: s_waitcnt vmcnt(0) (atomics stay counted until performed).  (An
         // agent-scope release fence here costs an L2 write-back per wave: 15 625 of them took 0.8 ms.)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // arrival, two levels: last wave of its shard -> last shard of the grid
-        const uint32_t shard = blockIdx.x % COUNT_SHARDS, shards_used = min(gridDim.x, (uint32_t)COUNT_SHARDS);
-        const uint32_t waves_of_shard = (gridDim.x - shard + COUNT_SHARDS - 1u) / COUNT_SHARDS;
-        arrived = 0u;
-        if (__hip_atomic_fetch_add(&sh->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == waves_of_shard - 1u)
-            arrived = (__hip_atomic_fetch_add(&cb->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards_used - 1u) ? 1u : 0u;
+        if (TOTALS) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // arrival, two levels: last wave of its shard -> last shard of the grid
+            const uint32_t shard = blockIdx.x % COUNT_SHARDS, shards_used = min(gridDim.x, (uint32_t)COUNT_SHARDS);
+            const uint32_t waves_of_shard = (gridDim.x - shard + COUNT_SHARDS - 1u) / COUNT_SHARDS;
+            if (__hip_atomic_fetch_add(&sh->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == waves_of_shard - 1u)
+                arrived = (__hip_atomic_fetch_add(&cb->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards_used - 1u) ? 1u : 0u;
+        }
     }
+    if (!TOTALS) return;
     arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
     if (!arrived) return;
     // ---- last wave: totals of the 256 shards (4 per lane; agent-scope atomic loads: the adds were made at that scope)
@@ -509,9 +514,49 @@ __device__ __forceinline__ void for_block_pairs(int64_t n, const u2* __restrict_
 __global__ __launch_bounds__(256) void bin_count_kernel(int64_t n, const u2* __restrict__ rect, const uint32_t* __restrict__ tiles,
                                                         const uint32_t* __restrict__ mask, int lists_x, int nb, uint32_t* __restrict__ bin_total,
                                                         uint32_t* __restrict__ block_off, uint32_t* __restrict__ list_count,
-                                                        uint2* __restrict__ ranges, int nl) {
+                                                        uint2* __restrict__ ranges, int nl, CounterBlock* cb, DevCounts* counts,
+                                                        DevCounts* counts_mapped) {
     __shared__ uint32_t hist[MAX_BINS];
     const int tid = threadIdx.x;
+    if (cb && blockIdx.x == 0) {                 // GSPLAT_PROJECT_COUNTS_LATE: totals of the projection's sharded counters; shards cleared
+        static_assert(COUNT_SHARDS == 256, "one shard per thread");
+        __shared__ unsigned long long tsum[4][4];
+        __shared__ uint32_t tmax[4];
+        CountShard* sh = cb->shards + tid;
+        unsigned long long t4[4];
+        t4[0] = (unsigned long long)(uint32_t)__hip_atomic_load(&sh->survivors, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t4[1] = (unsigned long long)(uint32_t)__hip_atomic_load(&sh->visible, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t4[2] = (unsigned long long)__hip_atomic_load(&sh->ref_pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t4[3] = (unsigned long long)__hip_atomic_load(&sh->bin_pairs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t mxt = (uint32_t)__hip_atomic_load(&sh->max_tiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sh->survivors, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sh->visible, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sh->ref_pairs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sh->bin_pairs, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sh->max_tiles, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int sft = 32; sft > 0; sft >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t4[k] += (unsigned long long)__shfl_xor((long long)t4[k], sft);
+            mxt = max(mxt, (uint32_t)__shfl_xor((int)mxt, sft));
+        }
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tsum[tid >> 6][k] = t4[k];
+            tmax[tid >> 6] = mxt;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            DevCounts c;
+            c.n_survivors = (int32_t)(tsum[0][0] + tsum[1][0] + tsum[2][0] + tsum[3][0]);
+            c.n_visible = (int32_t)(tsum[0][1] + tsum[1][1] + tsum[2][1] + tsum[3][1]);
+            c.n_pairs = (int64_t)(tsum[0][2] + tsum[1][2] + tsum[2][2] + tsum[3][2]);
+            c.max_tiles = (int32_t)max(max(tmax[0], tmax[1]), max(tmax[2], tmax[3]));
+            c.reserved = 0;
+            c.n_binned = (int64_t)(tsum[0][3] + tsum[1][3] + tsum[2][3] + tsum[3][3]);
+            *counts = c;
+            if (counts_mapped) *counts_mapped = c;
+        }
+    }
     for (int l = blockIdx.x * 256 + tid; l < (nb << BIN_SHIFT); l += gridDim.x * 256) {     // for the split kernels
         list_count[l] = 0u;
         if (l < nl) ranges[l] = uint2{0u, 0u};
@@ -1856,31 +1901,41 @@ int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_vie
     const bool mapped = (flags & GSPLAT_PROJECT_COUNTS_MAPPED) != 0;
     const bool colour_inside = !fused || (flags & GSPLAT_PROJECT_COLOUR_FUSED) != 0;
     const bool jac = fused && (flags & GSPLAT_PROJECT_SAVE_SH_JACOBIAN) != 0;
+    const bool late = (flags & GSPLAT_PROJECT_COUNTS_LATE) != 0 && n > 0;      // counters totalled by bin_count_kernel
     if (n > 0) {
         Records out{ps.rec, ps.rect, ps.depth, ps.tiles, ps.mask, nullptr, nullptr};
         DevCounts* cm = mapped ? (DevCounts*)counts_host : nullptr;
         CounterBlock* cb = (CounterBlock*)scratch;
         const dim3 grid(blocks64(n)), block(64);
-        if (!fused)
-            hipLaunchKernelGGL((project_kernel<false, true>), grid, block, 0, st, *g, c2w, ps.cam, vk, out, cb, ps.counts, cm, ps.bin_total, (int)nb, nullptr);
-        else if (colour_inside && jac)
-            hipLaunchKernelGGL((project_kernel<true, true, true>), grid, block, 0, st, *g, c2w, ps.cam, vk, out, cb, ps.counts, cm, ps.bin_total, (int)nb, ps.kj);
-        else if (colour_inside)
-            hipLaunchKernelGGL((project_kernel<true, true>), grid, block, 0, st, *g, c2w, ps.cam, vk, out, cb, ps.counts, cm, ps.bin_total, (int)nb, nullptr);
-        else
-            hipLaunchKernelGGL((project_kernel<true, false>), grid, block, 0, st, *g, c2w, ps.cam, vk, out, cb, ps.counts, cm, ps.bin_total, (int)nb, nullptr);
+#define LAUNCH_PROJECT(F, C, J, KJ)                                                                                                     \
+    do {                                                                                                                                \
+        if (late) hipLaunchKernelGGL((project_kernel<F, C, J, false>), grid, block, 0, st, *g, c2w, ps.cam, vk, out, cb, ps.counts, cm,  \
+                                     ps.bin_total, (int)nb, KJ);                                                                        \
+        else hipLaunchKernelGGL((project_kernel<F, C, J, true>), grid, block, 0, st, *g, c2w, ps.cam, vk, out, cb, ps.counts, cm,        \
+                                ps.bin_total, (int)nb, KJ);                                                                             \
+    } while (0)
+        if (!fused) LAUNCH_PROJECT(false, true, false, nullptr);
+        else if (colour_inside && jac) LAUNCH_PROJECT(true, true, true, ps.kj);
+        else if (colour_inside) LAUNCH_PROJECT(true, true, false, nullptr);
+        else LAUNCH_PROJECT(true, false, false, nullptr);
+#undef LAUNCH_PROJECT
         LAUNCH_CHECK("project_kernel");
-        if (counts_host && !mapped) HIP_TRY(hipMemcpyAsync(counts_host, ps.counts, sizeof(gsplat_counts), hipMemcpyDeviceToHost, st));
+        if (counts_host && !mapped && !late) HIP_TRY(hipMemcpyAsync(counts_host, ps.counts, sizeof(gsplat_counts), hipMemcpyDeviceToHost, st));
     } else {                        // no kernel runs: the counters are zero by definition
         HIP_TRY(hipMemsetAsync(ps.counts, 0, sizeof(DevCounts), st));
         HIP_TRY(hipMemsetAsync(ps.bin_total, 0, nb * sizeof(uint32_t), st));
         if (counts_host) HIP_TRY(hipMemsetAsync(counts_host, 0, sizeof(gsplat_counts), st));
     }
-    if (counts_event) HIP_TRY(hipEventRecord((hipEvent_t)counts_event, st));
+    if (counts_event && !late) HIP_TRY(hipEventRecord((hipEvent_t)counts_event, st));
     if (n > 0) {                    // these need no pair buffer: queued behind the event, they run while a waiting host sizes the buffers
         hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)n_bin_blocks(n)), dim3(256), 0, st, n, ps.rect, ps.tiles, ps.mask, vk.lists_x, (int)nb,
-                           ps.bin_total, ps.block_off, ps.list_count, ps.ranges, (int)nl);
+                           ps.bin_total, ps.block_off, ps.list_count, ps.ranges, (int)nl, late ? (CounterBlock*)scratch : nullptr, ps.counts,
+                           late && mapped ? (DevCounts*)counts_host : nullptr);
         LAUNCH_CHECK("bin_count_kernel");
+        if (late) {                 // the counters exist only now
+            if (counts_host && !mapped) HIP_TRY(hipMemcpyAsync(counts_host, ps.counts, sizeof(gsplat_counts), hipMemcpyDeviceToHost, st));
+            if (counts_event) HIP_TRY(hipEventRecord((hipEvent_t)counts_event, st));
+        }
         if (!colour_inside) {
             if (jac) hipLaunchKernelGGL(colour_kernel<true>, dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, ps.tiles, ps.rec, ps.kj);
             else hipLaunchKernelGGL(colour_kernel<false>, dim3(blocks64(n)), dim3(64), 0, st, *g, ps.cam, ps.tiles, ps.rec, nullptr);

@@ -200,7 +200,7 @@ class DeferredChecks:
             self._drain(len(self.pending) // 2)              # counter blocks come round again (they finished long ago)
 
     def _drain(self, count):
-        global _last_counts
+        global _last_counts, _last_binned
         for pinned, ev, cap, dev in self.pending[:count]:
             ev.synchronize()
             counts = _abi.Counts.from_buffer_copy(pinned.numpy().tobytes())
@@ -209,6 +209,7 @@ class DeferredChecks:
             self._overflow |= cap is not None and counts.n_binned > cap
             self._offscreen |= _abi.lib().gsplat_classify_counts(C.byref(counts)) == _abi.GSPLAT_SCENE_ALL_OFFSCREEN
             _last_counts = (counts.n_survivors, counts.n_visible, int(counts.n_pairs))
+            _last_binned = int(counts.n_binned)
         del self.pending[:count]
 
     def __enter__(self):
@@ -303,8 +304,9 @@ def _forward_begin(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad=Fal
         pend.pinned = _ws.next_pinned(dev)
         pend.ready = _ws.get_event(dev, fresh=deferred)
         # the counters go straight into the pinned block (mapped into the device's address space: no copy operation);
-        # a frame that will not wait for them evaluates the SH colour inside the projection kernel
-        flags = _abi.GSPLAT_PROJECT_COUNTS_MAPPED | (_abi.GSPLAT_PROJECT_COLOUR_FUSED if deferred else 0)
+        # a frame that will not wait for them evaluates the SH colour inside the projection kernel and lets the first binning
+        # kernel total the counters (the projection's waves then retire without waiting for their stores)
+        flags = _abi.GSPLAT_PROJECT_COUNTS_MAPPED | ((_abi.GSPLAT_PROJECT_COLOUR_FUSED | _abi.GSPLAT_PROJECT_COUNTS_LATE) if deferred else 0)
         # a backward pass will follow: the colour pass leaves 48 bytes per Gaussian that spare it the 192 bytes of SH coefficients
         fr.sh_jacobian = bool(fused and need_grad and _sh_jacobian)
         if fr.sh_jacobian:
@@ -476,9 +478,10 @@ class _RenderFn(torch.autograd.Function):
         ctx.frame = fr
         ctx.dtypes = [t.dtype if isinstance(t, torch.Tensor) else None for t in (pos, opacity_raw, a, b, c, d)]
         ctx.opa_shape = opacity_raw.shape
-        global _last_counts
+        global _last_counts, _last_binned
         if counts is not None:                   # (a deferred frame's counters are read in DeferredChecks.verify())
             ctx.counts = _last_counts = (counts.n_survivors, counts.n_visible, int(counts.n_pairs))
+            _last_binned = int(counts.n_binned)
         return image if pos.dtype == torch.float32 else image.to(pos.dtype)
 
     @staticmethod
@@ -596,6 +599,12 @@ def _pipeline_streams(dev):
 
 
 _last_counts = None
+_last_binned = None
+
+
+def binned_pairs():
+    """(list, Gaussian) pairs the most recent call really binned (after the exact ellipse / list test): P_b of DESIGN.md."""
+    return _last_binned
 
 
 def render_stats(image=None):

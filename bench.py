@@ -463,7 +463,8 @@ def main():
                                    f"{'forward+backward' if need_grad else 'forward only'}, one camera view per GPU per step"
                                    + ((", gradient exchange over " + ("RCCL" if args.backend == "nccl" else args.backend + " (rehearsal)"))
                                       if world > 1 and need_grad else ""),
-                       "N": N, "V": V, "P": P, "tiles": math.ceil(H / 16) * math.ceil(W / 16),
+                       "N": N, "V": V, "P": P, "P_binned": gs.ops.binned_pairs() if hasattr(gs, "ops") else None,
+                       "tiles": math.ceil(H / 16) * math.ceil(W / 16),
                        "parallelism": f"dp{world} by camera view", "allreduce": info.get(args.exchange),
                        "counts": "waited for in every forward pass" if args.wait_counts else
                                  "not waited for: buffers from earlier frames, checks once per step (ops.deferred_checks, as Trainer.step)"},

@@ -134,10 +134,15 @@ int64_t gsplat_bin_scratch_bytes(int64_t pair_capacity, const gsplat_view* v); /
  *                  GSPLAT_PROJECT_SAVE_SH_JACOBIAN (fused inputs; set it when a backward pass will follow): the colour pass
  *                  also leaves, per visible Gaussian, d colour / d logit and d logit / d position (48 bytes) in
  *                  project_state, so that gsplat_project_backward (flag GSPLAT_BACKWARD_SH_JACOBIAN) does not read the
- *                  192 bytes of SH coefficients again.  Ignored for un-fused inputs.                                   */
+ *                  192 bytes of SH coefficients again.  Ignored for un-fused inputs.
+ *                  GSPLAT_PROJECT_COUNTS_LATE (for callers that do NOT wait for the counters in the middle of the forward
+ *                  pass): the counters -- device copy, counts_host, counts_event -- are produced by the first binning kernel
+ *                  instead of by the projection kernel's last wave; the projection's waves then retire without waiting
+ *                  for their stores.  Everything queued after this call sees them as before.                           */
 #define GSPLAT_PROJECT_COLOUR_FUSED 1
 #define GSPLAT_PROJECT_COUNTS_MAPPED 2
 #define GSPLAT_PROJECT_SAVE_SH_JACOBIAN 4
+#define GSPLAT_PROJECT_COUNTS_LATE 8
 int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, void* project_state,
                    void* scratch, int64_t scratch_bytes, gsplat_counts* counts_host, void* counts_event, int32_t flags,
                    void* stream);

@@ -557,7 +557,8 @@ def test_backward_from_the_saved_sh_jacobian_is_the_backward_from_the_coefficien
 def test_counters_arrive_by_copy_or_by_mapped_store(gs):
     """gsplat_project hands the counters to the host either with a copy operation (any host memory, flags = 0: what the
     INTEGRATION.md stub does) or by storing them itself into device-mapped pinned memory (GSPLAT_PROJECT_COUNTS_MAPPED); with
-    or without the SH colour inside the projection kernel the counters are the same, and the counter block is left zeroed."""
+    or without the SH colour inside the projection kernel, totalled by the projection kernel or (COUNTS_LATE) by the first
+    binning kernel, the counters are the same, and the counter block is left zeroed."""
     import ctypes as C
     import importlib
     abi = importlib.import_module("3d-gaussian-splatting-for-novel-view-synthesis_amd._abi")
@@ -573,7 +574,10 @@ def test_counters_arrive_by_copy_or_by_mapped_store(gs):
     block = torch.zeros(lib.gsplat_project_scratch_bytes(n), dtype=torch.uint8, device=DEV)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     got = []
-    for flags in (0, abi.GSPLAT_PROJECT_COUNTS_MAPPED, abi.GSPLAT_PROJECT_COUNTS_MAPPED | abi.GSPLAT_PROJECT_COLOUR_FUSED, abi.GSPLAT_PROJECT_COLOUR_FUSED):
+    M, F, L, J = (abi.GSPLAT_PROJECT_COUNTS_MAPPED, abi.GSPLAT_PROJECT_COLOUR_FUSED, abi.GSPLAT_PROJECT_COUNTS_LATE,
+                  abi.GSPLAT_PROJECT_SAVE_SH_JACOBIAN)
+    # (COUNTS_LATE: the first binning kernel, queued by the same call, totals the counters instead of the projection's last wave)
+    for flags in (0, M, M | F, F, L, M | L, M | F | L, M | F | L | J, F | J):
         host = torch.full((C.sizeof(abi.Counts),), 255, dtype=torch.uint8).pin_memory()
         abi.check(lib.gsplat_project(C.byref(g), C.c_void_p(c2w.data_ptr()), C.byref(view), C.c_void_p(state.data_ptr()),
                                      C.c_void_p(block.data_ptr()), block.numel(), C.c_void_p(host.data_ptr()), None, flags, st), "gsplat_project")
