@@ -329,7 +329,12 @@ __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const f
     __shared__ float s_rest[FUSED && COLOUR ? 64 * 45 : 4];
     const int lane = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * 64, i = row0 + lane;
-    Camera cam;
+    stage_geometry<FUSED>(s, g, row0, lane);
+    if (FUSED && COLOUR) {                                   // all inputs of the wave in flight at once, one wait
+        stage_rows<3>(s_dc, g.f_dc, row0, g.n, lane);
+        stage_rows<45>(s_rest, g.f_rest, row0, g.n, lane);
+    }
+    Camera cam;                                              // (derived while the inputs are in flight)
     {
         float m[16];
 #pragma unroll
@@ -338,11 +343,6 @@ __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const f
         if (blockIdx.x == 0 && lane == 0) *cam_out = cam;
     }
     for (int b = blockIdx.x * 64 + lane; b < nb; b += gridDim.x * 64) bin_total[b] = 0u;
-    stage_geometry<FUSED>(s, g, row0, lane);
-    if (FUSED && COLOUR) {                                   // all inputs of the wave in flight at once, one wait
-        stage_rows<3>(s_dc, g.f_dc, row0, g.n, lane);
-        stage_rows<45>(s_rest, g.f_rest, row0, g.n, lane);
-    }
     __syncthreads();
     GaussIn in;
     Proj o;
@@ -1043,7 +1043,12 @@ constexpr int N_SUB = 8;                             // 4 x 2 sub-tiles of 4 x 4
 
 // Per-wave statistics for tools/raster_stats.py: only a diagnostics build (-DGSPLAT_DIAGNOSTICS, libgsplat_mi355x_diag.so)
 // can register a buffer; the product library always passes NULL.
-struct WaveStats { uint32_t list_len, chunks, visited, cycles; };
+struct WaveStats { uint32_t list_len, chunks, visited, cycles, begin_lo, launch_index; };   // chunks | duration in 100 MHz ticks << 12; begin: 100 MHz ticks; launch_index | XCD << 24
+__device__ __forceinline__ uint32_t xcc_id() {                // (every XCD has its own s_memtime counter)
+    uint32_t v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 0xFu;
+}
 #ifdef GSPLAT_DIAGNOSTICS
 WaveStats* g_stats_fwd = nullptr;
 WaveStats* g_stats_bwd = nullptr;
@@ -1206,6 +1211,7 @@ __global__ __launch_bounds__(64) void raster_forward_kernel(const uint2* __restr
     else if (prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (prio == 1) __builtin_amdgcn_s_setprio(1);
     const unsigned long long t_begin = stats ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long t_real = stats ? __builtin_amdgcn_s_memrealtime() : 0ull;      // 100 MHz, one clock for the whole chip
     uint32_t st_chunks = 0, st_visited = 0;
     const int grp = lane >> 3, j = lane & 7;
     const int px = tx * LIST_W + (grp & 3) * 4 + (j & 3);
@@ -1266,7 +1272,7 @@ __global__ __launch_bounds__(64) void raster_forward_kernel(const uint2* __restr
         alive_any = __any(T.x > 5e-5f || T.y > 5e-5f);        // dead pixels stay dead
     }
     if (stats && lane == 0)
-        stats[list] = WaveStats{rg.y - rg.x, st_chunks, st_visited, (uint32_t)(__builtin_amdgcn_s_memtime() - t_begin)};
+        stats[list] = WaveStats{rg.y - rg.x, (st_chunks & 0xFFFu) | ((uint32_t)(__builtin_amdgcn_s_memrealtime() - t_real) << 12), st_visited, (uint32_t)(__builtin_amdgcn_s_memtime() - t_begin), (uint32_t)t_real, blockIdx.x | (xcc_id() << 24)};
     if (va) {
         const int64_t o = ((int64_t)pya * W + px) * 3;
         image[o + 0] = fminf(fmaxf(Cr.x, 0.0f), 1.0f); image[o + 1] = fminf(fmaxf(Cg.x, 0.0f), 1.0f);
@@ -1336,7 +1342,7 @@ __device__ __forceinline__ float all_reduce8(float x) {
 
 // backward: longest queue per chunk (sizes the slot block below).  Measured at 16 / 20 / 24 / 28 / 32: 253 / 249-258 / 247 / 249 / 269 us
 // (config 3): below 12.8 KB of LDS per wave the occupancy gain is eaten by chunks cut short.
-constexpr int MAXQ_BWD = 28;                          // (even: the loop evaluates entries in pairs)
+constexpr int MAXQ_BWD = 24;                          // (even: the loop evaluates entries in pairs)
 
 // LDS of the backward kernel.  LDS float atomics are slow on this hardware (a ds_add_f32 wave-instruction with 64 lanes cost
 // ~100 LDS cycles here: 230 us of a 450 us kernel), so nothing is accumulated with them: every group writes the nine sums of
@@ -1344,12 +1350,17 @@ constexpr int MAXQ_BWD = 28;                          // (even: the loop evaluat
 // was queued in (it knows its rank in every queue) and leaves the row in `acc` for the flush.
 // LDS per wave decides the occupancy here (12.8 KB -> 12 waves per CU): the chunk's rows `acc` [entry][9] reuse the record
 // arrays, which are dead once the chunk's loop is over (the null record is rewritten by every stage_chunk).
+template <bool DET>
 struct RasterLdsBwd {
     RasterLds f;
     float slots[N_SUB * MAXQ_BWD * 9];   // [sub-tile][queue position][9 sums]
     uint32_t eid[CHUNK];                 // Gaussian id of every entry of the chunk
-    uint32_t eslot[CHUNK];               // (deterministic mode) the row's slot
+    uint32_t eslot[DET ? CHUNK : 1];     // (deterministic mode) the row's slot
 };
+// LDS is handed out in coarse pieces (1280 B by the look of it): at 12 848 B per wave 11 waves were resident per CU (measured with
+// tools/raster_stats.py: 2816 waves), at 12 608 B twelve (231 -> 221 us), at 11 456 B and 128 VGPRs fourteen (214 us); sixteen
+// (queue cap 18: 10 KB) lose more to chunks cut short than they gain (228 us).
+static_assert(sizeof(RasterLdsBwd<false>) <= 11520, "the backward kernel's LDS per wave decides its occupancy");
 static_assert(sizeof(f4) * 3 * (CHUNK + 1) >= sizeof(float) * CHUNK * 9, "acc must fit into the record arrays");
 
 // K7: same traversal as K6 (identical T_i and alive decisions).  For pixel p and Gaussian i:
@@ -1369,14 +1380,15 @@ struct DetArgs {
     uint32_t capacity;
 };
 
+// (4 waves per SIMD: the kernel needs 131 VGPRs left alone, 128 -- no spill -- when asked; with 11.4 KB of LDS 14 waves fit a CU)
 template <bool DET>
-__global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ ids,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void raster_backward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ ids,
                                                              const Rec64* __restrict__ rec, const uint32_t* __restrict__ order,
                                                              int lists_x, int H, int W, float chi, float alpha_max,
                                                              float alpha_cutoff, const float* __restrict__ accum,
                                                              const float* __restrict__ gimg, float* __restrict__ grad2d,
                                                              WaveStats* __restrict__ stats, uint32_t id_max, DetArgs det) {
-    __shared__ RasterLdsBwd sb;
+    __shared__ RasterLdsBwd<DET> sb;
     RasterLds& s = sb.f;
     const int lane = threadIdx.x;
     const uint32_t list = order[blockIdx.x];
@@ -1387,6 +1399,7 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
     else if (prio == 2) __builtin_amdgcn_s_setprio(2);
     else if (prio == 1) __builtin_amdgcn_s_setprio(1);
     const unsigned long long t_begin = stats ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long t_real = stats ? __builtin_amdgcn_s_memrealtime() : 0ull;      // 100 MHz, one clock for the whole chip
     uint32_t st_chunks = 0, st_visited = 0;
     const int tx = list % lists_x, hy = list / lists_x;
     const int grp = lane >> 3, j = lane & 7;
@@ -1547,7 +1560,7 @@ __global__ __launch_bounds__(64) void raster_backward_kernel(const uint2* __rest
         }
     }
     if (stats && lane == 0)
-        stats[list] = WaveStats{rg.y - rg.x, st_chunks, st_visited, (uint32_t)(__builtin_amdgcn_s_memtime() - t_begin)};
+        stats[list] = WaveStats{rg.y - rg.x, (st_chunks & 0xFFFu) | ((uint32_t)(__builtin_amdgcn_s_memrealtime() - t_real) << 12), st_visited, (uint32_t)(__builtin_amdgcn_s_memtime() - t_begin), (uint32_t)t_real, blockIdx.x | (xcc_id() << 24)};
 }
 
 // ---- deterministic mode: slots of the (list, Gaussian) rows and their fixed-order sum ------------------------------------
