@@ -306,3 +306,7 @@ GS_HD void evaluate_sh_backward_one(int64_t i, const float* f_dc, const float* f
 }
 
 }  // namespace gsm
+
+#if defined(__clang__)
+#pragma clang fp contract(fast)
+#endif

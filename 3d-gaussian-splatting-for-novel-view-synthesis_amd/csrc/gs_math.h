@@ -16,6 +16,14 @@
 #define GS_HD inline
 #endif
 
+// Everything in gs_math.h / gs_body.h is compiled with fp contraction "on": a * b + c written in ONE expression becomes an fma,
+// decided by the front end per source expression.  (hipcc's default, "fast", lets the back end fuse across statements depending
+// on the surrounding code, so the same function gave last-bit different results in different kernels -- a render under no_grad
+// differed from the same render with gradients, the frame-by-frame path from render_frames.)  gs_body.h restores the default.
+#if defined(__clang__)
+#pragma clang fp contract(on)
+#endif
+
 namespace gsm {
 
 // Camera block derived on the device from c2w (utils.py:25-29); read uniformly by every thread.
@@ -369,18 +377,21 @@ GS_HD void project_gaussian(const float p[3], const float S[6], float o_raw, con
     m.l1 = mid + m.rad; m.l2 = mid - m.rad;
     m.f1 = clampf_(m.l1, 1e-6f, 1e4f); m.f2 = clampf_(m.l2, 1e-6f, 1e4f);
     m.clamped = (m.f1 != m.l1) || (m.f2 != m.l2);
+    float a2, b2, d2;        // (locals, stored once: stores to m inside the branches were merged into a store through a pointer phi,
+                             //  which kept a field of m in scratch memory)
     if (!m.clamped) {
-        m.a2 = m.a; m.b2 = m.b; m.d2 = m.d;
+        a2 = m.a; b2 = m.b; d2 = m.d;
     } else if (m.rad > 0.f) {
         // f(S) = f2 I + k (S - l2 I), k = (f1 - f2) / (l1 - l2); (S - l2 I) computed without cancellation
         const float k = (m.f1 - m.f2) / (2.f * m.rad);
         float am, dm;   // a - l2, d - l2
         if (m.diff > 0.f) { am = m.rad + m.diff; dm = (m.b * m.b) / am; }
         else { dm = m.rad - m.diff; am = (m.b * m.b) / dm; }
-        m.a2 = m.f2 + k * am; m.d2 = m.f2 + k * dm; m.b2 = k * m.b;
+        a2 = m.f2 + k * am; d2 = m.f2 + k * dm; b2 = k * m.b;
     } else {
-        m.a2 = m.f1; m.d2 = m.f1; m.b2 = 0.f;
+        a2 = m.f1; d2 = m.f1; b2 = 0.f;
     }
+    m.a2 = a2; m.b2 = b2; m.d2 = d2;
     if (!(isfinite(m.a2) && isfinite(m.b2) && isfinite(m.d2))) return;       // render.py:187-201
     // F10 radius, AABB, on-screen test
     const float lam = fminf(fmaxf(m.f1, 1e-12f), 1e4f);

@@ -237,11 +237,14 @@ __device__ __forceinline__ void unstage_rows(float* __restrict__ g, const float*
     }
 }
 
+// (LDS is handed out in pieces of 1280 B: with fused inputs the projection kernels use 15 104 B -> 10 waves per CU; the 9-float
+// rows of the un-fused layout would cost the fused kernels a piece, and a wave per CU, for nothing)
+template <bool FUSED>
 struct ProjectLds {
     float pos[64 * 3];
     float opa[64];
-    float a[64 * 9];        // fused: q_raw [64][4]       un-fused: sigma [64][9]
-    float b[64 * 3];        // fused: scale_raw [64][3]   un-fused: colour [64][3]
+    float a[64 * (FUSED ? 4 : 9)];   // fused: q_raw [64][4]       un-fused: sigma [64][9]
+    float b[64 * 3];                 // fused: scale_raw [64][3]   un-fused: colour [64][3]
 };
 
 struct ShCoefLds {          // same access as ShCoefGlobal, on the staged copy
@@ -251,7 +254,7 @@ struct ShCoefLds {          // same access as ShCoefGlobal, on the staged copy
 };
 
 template <bool FUSED>
-__device__ __forceinline__ GaussIn gauss_from_lds(const ProjectLds& s, int lane) {
+__device__ __forceinline__ GaussIn gauss_from_lds(const ProjectLds<FUSED>& s, int lane) {
     GaussIn in;
 #pragma unroll
     for (int k = 0; k < 3; ++k) in.p[k] = s.pos[lane * 3 + k];
@@ -271,7 +274,7 @@ __device__ __forceinline__ GaussIn gauss_from_lds(const ProjectLds& s, int lane)
 }
 
 template <bool FUSED>
-__device__ __forceinline__ void stage_geometry(ProjectLds& s, const gsplat_gaussians& g, int64_t row0, int lane) {
+__device__ __forceinline__ void stage_geometry(ProjectLds<FUSED>& s, const gsplat_gaussians& g, int64_t row0, int lane) {
     stage_rows<3>(s.pos, g.pos, row0, g.n, lane);
     stage_rows<1>(s.opa, g.opacity_raw, row0, g.n, lane);
     if (FUSED) {
@@ -324,7 +327,7 @@ template <bool FUSED, bool COLOUR, bool JAC = false, bool TOTALS = true>
 __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const float* __restrict__ c2w, Camera* __restrict__ cam_out, ViewK vk,
                                                      Records out, CounterBlock* cb, DevCounts* counts, DevCounts* counts_mapped,
                                                      uint32_t* __restrict__ bin_total, int nb, float* __restrict__ kj_out) {
-    __shared__ ProjectLds s;
+    __shared__ ProjectLds<FUSED> s;
     __shared__ float s_dc[FUSED && COLOUR ? 64 * 3 : 4];
     __shared__ float s_rest[FUSED && COLOUR ? 64 * 45 : 4];
     const int lane = threadIdx.x;
@@ -1340,8 +1343,7 @@ __device__ __forceinline__ float all_reduce8(float x) {
 #undef DPP_ADD_F32
 #undef DPP_MOV_F32
 
-// backward: longest queue per chunk (sizes the slot block below).  Measured at 16 / 20 / 24 / 28 / 32: 253 / 249-258 / 247 / 249 / 269 us
-// (config 3): below 12.8 KB of LDS per wave the occupancy gain is eaten by chunks cut short.
+// backward: longest queue per chunk (sizes the slot block below; see the occupancy note at RasterLdsBwd).
 constexpr int MAXQ_BWD = 24;                          // (even: the loop evaluates entries in pairs)
 
 // LDS of the backward kernel.  LDS float atomics are slow on this hardware (a ds_add_f32 wave-instruction with 64 lanes cost
@@ -1649,7 +1651,7 @@ template <bool FUSED, bool JAC = false>
 __global__ __launch_bounds__(64) void project_backward_kernel(gsplat_gaussians g, const Camera* __restrict__ camp, ViewK vk,
                                                               const uint32_t* __restrict__ tiles, const float* __restrict__ grad2d,
                                                               gsplat_gaussian_grads out, bool factored, const float* __restrict__ kj_in) {
-    __shared__ ProjectLds s;
+    __shared__ ProjectLds<FUSED> s;
     __shared__ float s_dc[FUSED ? 64 * 3 : 4];
     __shared__ float s_rest[FUSED ? 64 * 45 : 4];
     const int lane = threadIdx.x;

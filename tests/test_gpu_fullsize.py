@@ -56,9 +56,18 @@ def cal3():
                 grads={k: util.grad_errors(g32[k], g64[k]) for k in NAMES})
 
 
+P_KNIFE_EDGE = 8      # (tile, Gaussian) pairs: fp32 rounding of u +- ceil(2.5 sqrt(lambda)) against a tile border (of 2.7 M pairs at
+                      # config 3: two since the projection math is compiled with fp contraction "on", none by luck before; the float64
+                      # oracle itself is off by up to 64, see test_full_frame_parity_vs_c_oracle)
+
+
+def _counts_match(got, ref):
+    return got[0] == ref[0] and abs(got[1] - ref[1]) <= P_KNIFE_EDGE
+
+
 def test_config3_counts_match_the_reference(cfg3):
     _, _, _, img, stats = cfg3
-    assert stats[1] == 973_068 and stats[2] == 2_720_508          # measured by running the reference
+    assert _counts_match(stats[1:], (973_068, 2_720_508)), stats  # measured by running the reference
     assert torch.isfinite(img).all() and float(img.min()) >= 0.0 and float(img.max()) <= 1.0
     assert 0.05 < float(img.mean()) < 0.95
 
@@ -162,7 +171,7 @@ def test_full_frame_parity_vs_c_oracle(gs, cfg, counts, cal3):
     # on the same scene -- the whole frame for config 2, the 1920 x 32 window of `cal3` for config 3 (the float32 oracle needs 45 GB
     # and minutes for the whole 1080p frame; flip densities and relative gradient errors carry over from the window).
     img = gs.render_gaussians(*[p[k] for k in NAMES], torch.eye(4, device=DEV), *cam)
-    assert gs.render_stats(img)[1:] == counts
+    assert _counts_match(gs.render_stats(img)[1:], counts), gs.render_stats(img)
     (img * torch.tensor(w, device=DEV)).sum().backward()
     st, ref, g, (V, P) = c_oracle.render(s, *cam, grad_image=w.astype(np.float64))
     # the float64 oracle may differ from the fp32 counts in a handful of knife-edge ceil() radii
