@@ -485,33 +485,44 @@ __global__ __launch_bounds__(64) void colour_kernel(gsplat_gaussians g, const Ca
 // its share of every bin it touches with ONE returning global atomic per bin (device-scope atomics run at ~20 G/s and
 // serialise per address: one per pair was 10x slower than the radix sort this replaces; one per block and bin is noise).
 // Needs no pair buffer, so it is queued with the colour pass behind the counters and runs during the host round trip.
-template <class F>
-__device__ __forceinline__ void for_block_pairs(int64_t n, const u2* __restrict__ rect, const uint32_t* __restrict__ tiles,
-                                                const uint32_t* __restrict__ mask, const float* __restrict__ depth, int lists_x, F f) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    constexpr int K = BIN_GAUSS / 256;
+struct BlockPairs {                    // the 8 Gaussians of one thread of a binning workgroup
+    static constexpr int K = BIN_GAUSS / 256;
     uint32_t nt[K], mk[K];
     u2 r[K];
     uint64_t payload[K];
+};
+
+// ALL loads of the thread's Gaussians in flight together: one round trip, and the caller can put its own set-up (prefix sums,
+// clearing LDS, barriers) between this and for_block_pairs.  The rectangle, mask and depth of a Gaussian that is not binned are
+// stale values: read and ignored.
+__device__ __forceinline__ BlockPairs load_block_pairs(int64_t n, const u2* __restrict__ rect, const uint32_t* __restrict__ tiles,
+                                                       const uint32_t* __restrict__ mask, const float* __restrict__ depth) {
+    constexpr int K = BlockPairs::K;
+    BlockPairs bp;
+    float dz[K];
+    const int tid = threadIdx.x;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {            // all loads of the thread's 8 Gaussians in flight together
+    for (int k = 0; k < K; ++k) {
         const int64_t i = (int64_t)blockIdx.x * BIN_GAUSS + k * 256 + tid;
-        nt[k] = i < n ? tiles[i] : 0u;
+        const bool in = i < n;
+        bp.nt[k] = in ? tiles[i] : 0u;
+        bp.r[k] = in ? rect[i] : u2{0u, 0u};
+        bp.mk[k] = in ? mask[i] : 0u;
+        dz[k] = (in && depth) ? depth[i] : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int64_t i = (int64_t)blockIdx.x * BIN_GAUSS + k * 256 + tid;
-        r[k] = u2{0u, 0u};
-        payload[k] = 0ull;
-        mk[k] = 0u;
-        if (nt[k]) {
-            r[k] = rect[i];
-            mk[k] = mask[i];
-            if (depth) payload[k] = ((uint64_t)f2u(depth[i]) << 32) | (uint64_t)(uint32_t)i;
-        }
+        bp.payload[k] = ((uint64_t)f2u(dz[k]) << 32) | (uint64_t)(uint32_t)i;
     }
+    return bp;
+}
+
+template <class F>
+__device__ __forceinline__ void for_block_pairs(const BlockPairs& bp, int lists_x, F f) {
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int k = 0; k < K; ++k) for_each_list(r[k], nt[k], mk[k], lists_x, lane, payload[k], 0u, f);
+    for (int k = 0; k < BlockPairs::K; ++k) for_each_list(bp.r[k], bp.nt[k], bp.mk[k], lists_x, lane, bp.payload[k], 0u, f);
 }
 
 __global__ __launch_bounds__(256) void bin_count_kernel(int64_t n, const u2* __restrict__ rect, const uint32_t* __restrict__ tiles,
@@ -521,6 +532,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(int64_t n, const u2* __r
                                                         DevCounts* counts_mapped) {
     __shared__ uint32_t hist[MAX_BINS];
     const int tid = threadIdx.x;
+    const BlockPairs bp = load_block_pairs(n, rect, tiles, mask, nullptr);
     if (cb && blockIdx.x == 0) {                 // GSPLAT_PROJECT_COUNTS_LATE: totals of the projection's sharded counters; shards cleared
         static_assert(COUNT_SHARDS == 256, "one shard per thread");
         __shared__ unsigned long long tsum[4][4];
@@ -566,7 +578,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(int64_t n, const u2* __r
     }
     for (int b = tid; b < nb; b += 256) hist[b] = 0u;
     __syncthreads();
-    for_block_pairs(n, rect, tiles, mask, nullptr, lists_x, [&](uint32_t l, uint32_t, uint64_t, uint32_t) { atomicAdd(&hist[l >> BIN_SHIFT], 1u); });
+    for_block_pairs(bp, lists_x, [&](uint32_t l, uint32_t, uint64_t, uint32_t) { atomicAdd(&hist[l >> BIN_SHIFT], 1u); });
     __syncthreads();
     for (int b = tid; b < nb; b += 256) {
         const uint32_t c = hist[b];
@@ -584,10 +596,19 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(int64_t n, const u2* _
                                                           uint64_t* __restrict__ bvals) {
     __shared__ uint32_t cur[MAX_BINS], wsum[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // exclusive prefix of the bin totals: thread t owns a contiguous run of ceil(nb / 256) bins
+    const BlockPairs bp = load_block_pairs(n, rect, tiles, mask, depth);
+    // exclusive prefix of the bin totals: thread t owns a contiguous run of ceil(nb / 256) bins.  The first four of a thread's
+    // totals and block offsets are loaded up front (all of them up to 1024 bins = 4 M pixels): one round trip, not three.
     const int per = (nb + 255) / 256, first = tid * per;
-    uint32_t run = 0u;
-    for (int k = 0; k < per; ++k) run += first + k < nb ? bin_total[first + k] : 0u;
+    uint32_t bt[4], bo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const bool in = k < per && first + k < nb;
+        bt[k] = in ? bin_total[first + k] : 0u;
+        bo[k] = in ? block_off[(int64_t)blockIdx.x * nb + first + k] : 0u;
+    }
+    uint32_t run = bt[0] + bt[1] + bt[2] + bt[3];
+    for (int k = 4; k < per; ++k) run += first + k < nb ? bin_total[first + k] : 0u;
     uint32_t incl = run;
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t up_ = (uint32_t)__shfl_up((int)incl, d);
@@ -600,8 +621,8 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(int64_t n, const u2* _
     for (int k = 0; k < per; ++k) {
         const int b = first + k;
         if (b < nb) {
-            const uint32_t c = bin_total[b];
-            cur[b] = st + block_off[(int64_t)blockIdx.x * nb + b];        // garbage for bins this block never touches: unused
+            const uint32_t c = k < 4 ? bt[k & 3] : bin_total[b];
+            cur[b] = st + (k < 4 ? bo[k & 3] : block_off[(int64_t)blockIdx.x * nb + b]);   // garbage for bins this block never touches: unused
             if (blockIdx.x == 0) {
                 bin_start[b] = st;
                 if (b == nb - 1) bin_start[nb] = st + c;
@@ -610,7 +631,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(int64_t n, const u2* _
         }
     }
     __syncthreads();
-    for_block_pairs(n, rect, tiles, mask, depth, lists_x, [&](uint32_t l, uint32_t, uint64_t pl, uint32_t) {
+    for_block_pairs(bp, lists_x, [&](uint32_t l, uint32_t, uint64_t pl, uint32_t) {
         const uint32_t pos = atomicAdd(&cur[l >> BIN_SHIFT], 1u);
         if (pos < n_binned)                                 // defensive: never write past the caller's buffer
             bvals[pos] = pl | ((uint64_t)(l & ((1u << BIN_SHIFT) - 1u)) << ID_BITS);
@@ -624,13 +645,18 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(int64_t n, const u2* _
 // start + prefix of the bin's final list counts; a pair goes to list start + segment offset + arrival rank (LDS atomic).
 // The segment that begins a bin also writes the [start, end) of the bin's lists.  Segment id = chunk + bin (unique: from
 // one segment to the next at least one of the two grows).
-__device__ __forceinline__ int bin_of_pair(const uint32_t* __restrict__ bin_start, int nb, uint32_t p) {
-    int lo = 0, hi = nb;                       // last b in [0, nb) with bin_start[b] <= p
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (bin_start[mid] <= p) lo = mid; else hi = mid;
-    }
-    return lo;
+//
+// Which bin holds pair p (the b with bin_start[b] <= p < bin_start[b + 1]): every thread looks at its bins, the one that finds it
+// reports it -- ONE round trip (a binary search is 8 dependent loads at config 3: 4-5 us at the start of every workgroup).
+// Ends with a barrier.
+template <int THREADS>
+__device__ __forceinline__ int bin_of_pair_parallel(const uint32_t* __restrict__ bin_start, int nb, uint32_t p, int* slot) {
+    if (threadIdx.x == 0) *slot = 0;
+    __syncthreads();
+    for (int t = threadIdx.x; t < nb; t += THREADS)
+        if (bin_start[t] <= p && p < bin_start[t + 1]) *slot = t;
+    __syncthreads();
+    return *slot;
 }
 
 __device__ __forceinline__ uint32_t local_list(uint64_t v) { return (uint32_t)(v >> ID_BITS) & ((1u << BIN_SHIFT) - 1u); }
@@ -649,18 +675,19 @@ __global__ __launch_bounds__(256) void split_count_kernel(int nb, const uint32_t
                                                           uint32_t* __restrict__ list_count, uint32_t* __restrict__ seg_off) {
     constexpr int L = 1 << BIN_SHIFT, U = SPLIT_CHUNK / 256;
     __shared__ uint32_t cnt[L];
+    __shared__ int s_b0;
     const int tid = threadIdx.x;
     const uint32_t n_binned = pairs_to_process(counts, capacity);
     const uint32_t c0 = blockIdx.x * (uint32_t)SPLIT_CHUNK, c1 = min(c0 + (uint32_t)SPLIT_CHUNK, n_binned);
     if (c0 >= n_binned) return;
-    for (int b = bin_of_pair(bin_start, nb, c0); b < nb && bin_start[b] < c1; ++b) {
+    for (int b = bin_of_pair_parallel<256>(bin_start, nb, c0, &s_b0); b < nb && bin_start[b] < c1; ++b) {
         const uint32_t s = max(c0, bin_start[b]), e = min(c1, bin_start[b + 1]);
         if (s >= e) continue;                                  // empty bin (uniform)
-        if (tid < L) cnt[tid] = 0u;
-        __syncthreads();
-        uint32_t k[U];
+        uint32_t k[U];                                          // (loads issued before the barrier: one round trip less)
 #pragma unroll
         for (int u = 0; u < U; ++u) k[u] = s + u * 256 + tid < e ? local_list(bvals[s + u * 256 + tid]) : 0xFFFFFFFFu;
+        if (tid < L) cnt[tid] = 0u;
+        __syncthreads();
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (k[u] != 0xFFFFFFFFu) atomicAdd(&cnt[k[u]], 1u);
@@ -776,9 +803,13 @@ __global__ __launch_bounds__(SS_THREADS) void split_scatter_kernel(int nl, int n
     const uint32_t chunk = blockIdx.x - 1u;
     const uint32_t c0 = chunk * (uint32_t)SPLIT_CHUNK, c1 = min(c0 + (uint32_t)SPLIT_CHUNK, n_binned);
     if (c0 >= n_binned) return;
-    for (int b = bin_of_pair(bin_start, nb, c0); b < nb && bin_start[b] < c1; ++b) {
+    int* const s_b0 = reinterpret_cast<int*>(lds + L);
+    for (int b = bin_of_pair_parallel<SS_THREADS>(bin_start, nb, c0, s_b0); b < nb && bin_start[b] < c1; ++b) {
         const uint32_t bs = bin_start[b], s = max(c0, bs), e = min(c1, bin_start[b + 1]);
         if (s >= e) continue;
+        uint64_t v[U];                                          // (loads issued before the scan and the barrier: one round trip less)
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = s + u * SS_THREADS + tid < e ? bvals[s + u * SS_THREADS + tid] : ~0ull;
         if (tid < L) {                                          // one wave: exclusive scan of the bin's 64 list sizes
             const uint32_t c = list_count[b * L + tid];
             uint32_t incl = c;
@@ -792,9 +823,6 @@ __global__ __launch_bounds__(SS_THREADS) void split_scatter_kernel(int nl, int n
             if (s == bs && list < nl) ranges[list] = uint2{min(st, capacity), min(st + c, capacity)};    // (clipped: overflow only)
         }
         __syncthreads();
-        uint64_t v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = s + u * SS_THREADS + tid < e ? bvals[s + u * SS_THREADS + tid] : ~0ull;
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (s + u * SS_THREADS + tid < e) {
@@ -1993,7 +2021,7 @@ int gsplat_bin(int64_t n, int64_t pair_capacity, const gsplat_view* v, const voi
     uint64_t* vals = sc.vals;
     const auto cap = [&](int64_t min_len) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(nl, n_binned / min_len)); };
     if (n_binned >= 1024) {       // lists of 1024+ entries: 100 KB of LDS per workgroup; 8192+ fall back to global memory inside
-        hipLaunchKernelGGL((list_sort_kernel<512, 16, 13>), dim3(std::min(cap(1024), 256u)), dim3(512), 0, st, ps.order, ps.class_bounds, ps.ranges,
+        hipLaunchKernelGGL((list_sort_kernel<1024, 8, 13>), dim3(std::min(cap(1024), 256u)), dim3(1024), 0, st, ps.order, ps.class_bounds, ps.ranges,
                            vals, sorted_ids);
         LAUNCH_CHECK("list_sort_kernel<8192>");
     }
