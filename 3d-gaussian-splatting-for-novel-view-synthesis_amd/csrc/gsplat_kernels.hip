@@ -1207,9 +1207,10 @@ __device__ __forceinline__ T lds_at(const T* base, uint32_t byte_off) {
 }
 
 // min as ONE v_min_f32 (fminf() first canonicalises a scalar operand with a v_max_f32 every time it is used; no NaNs here)
+// b is wave-uniform (a kernel argument): taken from its SGPR as src0, not copied to a VGPR first
 __device__ __forceinline__ float vmin(float a, float b) {
     float r;
-    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    asm("v_min_f32 %0, %2, %1" : "=v"(r) : "v"(a), "s"(b));
     return r;
 }
 
@@ -1217,6 +1218,7 @@ __device__ __forceinline__ int launch_priority(uint32_t b, uint32_t grid) {
     return b * 64u < grid ? 3 : (b * 16u < grid ? 2 : (b * 4u < grid ? 1 : 0));
 }
 
+// (6 waves per SIMD as the compiler leaves it: 76 VGPRs.  Forced to 7 -- 69 VGPRs, no spill -- 90 us against 87.5; to 8: spills, 99 us)
 __global__ __launch_bounds__(64) void raster_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ ids,
                                                             const Rec64* __restrict__ rec, const uint32_t* __restrict__ order,
                                                             int lists_x, int H, int W, float chi, float alpha_max,
@@ -1286,14 +1288,15 @@ __global__ __launch_bounds__(64) void raster_forward_kernel(const uint2* __restr
             v2f al0 = b0.y * g0, al1 = b1.y * g1;
             al0.x = vmin(al0.x, alpha_max); al0.y = vmin(al0.y, alpha_max);
             al1.x = vmin(al1.x, alpha_max); al1.y = vmin(al1.y, alpha_max);
-            // alpha = 0 outside the chi-square clip and below the cutoff (one select for both)
-            al0.x = (i00 && al0.x >= alpha_cutoff) ? al0.x : 0.0f; al0.y = (i01 && al0.y >= alpha_cutoff) ? al0.y : 0.0f;
-            al1.x = (i10 && al1.x >= alpha_cutoff) ? al1.x : 0.0f; al1.y = (i11 && al1.y >= alpha_cutoff) ? al1.y : 0.0f;
-            v2f w0 = al0 * T;
-            w0.x = (T.x > 5e-5f) ? w0.x : 0.0f; w0.y = (T.y > 5e-5f) ? w0.y : 0.0f;
+            // alpha = 0 outside the chi-square clip, below the cutoff, and on a dead pixel (T <= 5e-5: the term is masked, and a dead
+            // pixel stays dead whether or not its T keeps shrinking) -- ONE select for the three, and w = alpha T needs none
+            al0.x = (i00 && al0.x >= alpha_cutoff && T.x > 5e-5f) ? al0.x : 0.0f;
+            al0.y = (i01 && al0.y >= alpha_cutoff && T.y > 5e-5f) ? al0.y : 0.0f;
+            const v2f w0 = al0 * T;
             T = T - al0 * T;
-            v2f w1 = al1 * T;
-            w1.x = (T.x > 5e-5f) ? w1.x : 0.0f; w1.y = (T.y > 5e-5f) ? w1.y : 0.0f;
+            al1.x = (i10 && al1.x >= alpha_cutoff && T.x > 5e-5f) ? al1.x : 0.0f;
+            al1.y = (i11 && al1.y >= alpha_cutoff && T.y > 5e-5f) ? al1.y : 0.0f;
+            const v2f w1 = al1 * T;
             T = T - al1 * T;
             Cr += w0 * b0.z; Cg += w0 * b0.w; Cb += w0 * cb0;
             Cr += w1 * b1.z; Cg += w1 * b1.w; Cb += w1 * cb1;
@@ -1495,6 +1498,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             g.y = __builtin_amdgcn_exp2f(q.y);
             const v2f og = go * g;
             // alpha = min(o g, alpha_max) where q <= chi and that is >= alpha_cutoff (<=> o g >= alpha_cutoff: cutoff <= alpha_max), else 0
+            // (NOT folded with the alive test as in the forward kernel: alpha would then wait for the previous entry's T, and the
+            //  chain alpha -> 1 / (1 - alpha) -> d alpha of two consecutive entries could no longer overlap: +7 us, measured)
             const bool p0 = i0 && og.x >= alpha_cutoff, p1 = i1 && og.y >= alpha_cutoff;
             const float cl0 = vmin(og.x, amax), cl1 = vmin(og.y, amax);                 // (unconditional: a select, not a branch)
             v2f al;
@@ -1527,7 +1532,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             r[6] = hadd(ar); r[7] = hadd(ag);                              // d r, d g
             const float tot_b = all_reduce8(hadd(ab));                     // d b
             myslot[k * 9] = reduce_scatter8(r, lane);
-            if (j == 0) myslot[k * 9 + 8] = tot_b;
+            if (j == 0) myslot[k * 9 + 8] = tot_b;         // (two unconditional stores instead -- 3 instructions fewer -- measured no gain)
             T = T - al * T;
         };
         // Software pipeline over the queue (LDS latency is not covered by occupancy here: 3 waves per SIMD), two entries per step
