@@ -324,7 +324,9 @@ __device__ __forceinline__ void for_each_list(u2 rect, uint32_t nt, uint32_t mas
 // right behind, totals and clears them.  (With the totals in here every wave waits for ALL its stores and atomics and then for
 // a returning arrival atomic before it can retire: a quarter of a wave's life.)
 // (Workgroups of 2 / 4 waves instead of one: 89 / 91 us against 90 -- the kernel is not held by the rate at which one-wave
-// workgroups can be dispatched.)
+// workgroups can be dispatched.  As a STREAM -- 6 persistent waves per CU, two sets of LDS rows, block k + 1 requested before
+// block k is computed -- 158 us against 96: with 1.5 waves per SIMD the long dependent chains of the geometry math issue at a
+// fraction of the VALU rate; this kernel lives on wave-level parallelism.)
 template <bool FUSED, bool COLOUR, bool JAC = false, bool TOTALS = true>
 __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const float* __restrict__ c2w, Camera* __restrict__ cam_out, ViewK vk,
                                                      Records out, CounterBlock* cb, DevCounts* counts, DevCounts* counts_mapped,
