@@ -49,3 +49,10 @@ for tag in ("f32", "hip"):
     for k in names:
         e = g[k] - ref[1][k]
         print("   %-12s rel-L2 %.3e  max/max %.3e" % (k, np.linalg.norm(e) / (np.linalg.norm(ref[1][k]) + 1e-300), np.abs(e).max() / (np.abs(ref[1][k]).max() + 1e-300)))
+# where the largest error of every gradient sits, and what the float32 oracle does at the same Gaussian
+for k in names:
+    e = np.abs(res["hip"][1][k] - ref[1][k]).reshape(len(ref[1][k]), -1).max(1)
+    i = int(e.argmax())
+    e32 = np.abs(res["f32"][1][k] - ref[1][k]).reshape(len(ref[1][k]), -1).max(1)
+    print("   worst %-12s Gaussian %5d: |err| hip %.3e, f32 oracle %.3e there (its own worst %.3e at %d); |ref| there %.3e, max |ref| %.3e"
+          % (k, i, e[i], e32[i], e32.max(), int(e32.argmax()), np.abs(ref[1][k]).reshape(len(e), -1).max(1)[i], np.abs(ref[1][k]).max()))
