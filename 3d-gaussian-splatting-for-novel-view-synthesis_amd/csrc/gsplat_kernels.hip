@@ -1089,6 +1089,9 @@ __global__ __launch_bounds__(256) void list_sort_small_kernel(const uint32_t* __
 // Launch order: block b takes list order[b] (longest first, from plan_kernel), and the first blocks raise their wave
 // priority so that a dense list is not slowed down by light co-resident waves.
 typedef float v2f __attribute__((ext_vector_type(2)));
+// Exact ellipse / sub-tile test at staging time (subtile_mask_exact), measured on one box: the backward, whose iterations cost
+// 2.5x the forward's, gains (217 -> 207 us); the forward loses (85.6 -> 91.5 us) and keeps the box test.
+constexpr bool BWD_EXACT = true, FWD_EXACT = false;
 constexpr int CHUNK = 64;                            // list entries staged per round (one per lane)
 constexpr int QCAP = CHUNK + 8;                      // queue capacity: the inner loops read entries in pairs
 constexpr uint32_t NULL_OFF = CHUNK * 16;            // byte offset of the null record
@@ -1162,9 +1165,45 @@ __device__ __forceinline__ uint32_t subtile_mask(const Candidate& c, float ox, f
 // comes back in the next chunk).  Returns {entries taken, length of the longest queue} (uniform); m8 = the lane's sub-tile
 // mask (0 beyond the entries taken), ranks = the lane's position in each of its queues (8 bits per sub-tile).
 struct Staged { int n, maxc; };
-template <int MAXQ>
+// The same question answered exactly: does {q <= chi} (padded by 1e-3 like the list test of the projection, gs_math.h) reach the
+// pixel centres of sub-tile s?  q is convex, so outside the sub-tile its minimum lies on an edge that FACES the centre: at most
+// one vertical and one horizontal edge, each a clamped 1-D quadratic (v_med3).  ~125 instructions per entry for the 8 sub-tiles;
+// removes ~14 % of the (sub-tile, Gaussian) pairs the box test lets through.  Non-PD conics keep the box answer.
+__device__ __forceinline__ uint32_t subtile_mask_exact(const Candidate& c, float ox, float oy, float chi_pad) {
+    const float u = c.q0.x - ox, v = c.q0.y - oy, A = c.q0.z, B = c.q0.w, C = c.q1.x;
+    const float tB_C = -B * __builtin_amdgcn_rcpf(C), tB_A = -B * __builtin_amdgcn_rcpf(A), B2 = 2.0f * B;
+    float dx0[4], dx1[4], ax[4], bx[4], tx[4];
+    bool inx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        dx0[k] = (float)(4 * k) - u; dx1[k] = (float)(4 * k + 3) - u;
+        inx[k] = dx0[k] <= 0.f && dx1[k] >= 0.f;
+        const float X = dx0[k] > 0.f ? dx0[k] : dx1[k];
+        ax[k] = A * X * X; bx[k] = B2 * X; tx[k] = tB_C * X;
+    }
+    uint32_t m = 0u;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const float dy0 = (float)(4 * r) - v, dy1 = (float)(4 * r + 3) - v;
+        const bool iny = dy0 <= 0.f && dy1 >= 0.f;
+        const float Y = dy0 > 0.f ? dy0 : dy1;
+        const float cy = C * Y * Y, by = B2 * Y, sy = tB_A * Y;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float t = __builtin_amdgcn_fmed3f(tx[k], dy0, dy1);          // minimiser of q on the edge x = X, clamped to the edge
+            const float qx = ax[k] + (bx[k] + C * t) * t;
+            const float sc = __builtin_amdgcn_fmed3f(sy, dx0[k], dx1[k]);
+            const float qy = cy + (by + A * sc) * sc;
+            const float best = fminf(inx[k] ? 3.0e38f : qx, iny ? 3.0e38f : qy);
+            if ((inx[k] && iny) || !(best > chi_pad)) m |= 1u << (4 * r + k);   // NaN -> touched
+        }
+    }
+    return (A > 0.f && C > 0.f && A * C - B * B > 0.f) ? m : 0xFFu;
+}
+
+template <int MAXQ, bool EXACT = false>
 __device__ __forceinline__ Staged stage_chunk(RasterLds& s, const Candidate& c, int n, int lane, float ox, float oy, uint32_t& m8,
-                                              uint64_t& ranks) {
+                                              uint64_t& ranks, float chi_pad = 0.f) {
     __syncthreads();       // previous chunk's LDS reads are done (single-wave block: orders LDS traffic only)
     m8 = 0u;
     if (lane == 63) { s.r0[CHUNK] = f4{0.f, 0.f, 0.f, 0.f}; s.r1[CHUNK] = f4{0.f, 0.f, 0.f, 0.f}; s.r2[CHUNK] = f4{0.f, 0.f, 0.f, 0.f}; }
@@ -1174,6 +1213,7 @@ __device__ __forceinline__ Staged stage_chunk(RasterLds& s, const Candidate& c, 
         s.r1[lane] = f4{QK * c.q1.x, c.q1.y, c.q2.x, c.q2.y};
         s.r2[lane] = f4{c.q2.z, __uint_as_float(c.id), 0.f, 0.f};
         m8 = subtile_mask(c, ox, oy);
+        if (EXACT) m8 &= subtile_mask_exact(c, ox, oy, chi_pad);
     }
     {   // every queue slot -> the null record (QCAP 16-byte pieces)
         const uint32_t nn = NULL_OFF | (NULL_OFF << 16);
@@ -1287,7 +1327,7 @@ __global__ __launch_bounds__(64) void raster_forward_kernel(const uint2* __restr
     while (alive_any && base < rg.y) {
         uint32_t m8;
         uint64_t ranks;
-        const int maxc = stage_chunk<CHUNK>(s, cand, (int)min(rg.y - base, (uint32_t)CHUNK), lane, ox, oy, m8, ranks).maxc;
+        const int maxc = stage_chunk<CHUNK, FWD_EXACT>(s, cand, (int)min(rg.y - base, (uint32_t)CHUNK), lane, ox, oy, m8, ranks, chi * 1.001f + 1e-4f).maxc;
         base += CHUNK;
         if (base < rg.y) cand = fetch_candidate(lane, base, rg.y, ids, rec, id_max);   // in flight during the loop below
         ++st_chunks;
@@ -1397,7 +1437,8 @@ __device__ __forceinline__ float all_reduce8(float x) {
 #undef DPP_MOV_F32
 
 // backward: longest queue per chunk (sizes the slot block below; see the occupancy note at RasterLdsBwd).
-constexpr int MAXQ_BWD = 24;                          // (even: the loop evaluates entries in pairs)
+constexpr int MAXQ_BWD = 24;
+                          // (even: the loop evaluates entries in pairs)
 
 // LDS of the backward kernel.  LDS float atomics are slow on this hardware (a ds_add_f32 wave-instruction with 64 lanes cost
 // ~100 LDS cycles here: 230 us of a 450 us kernel), so nothing is accumulated with them: every group writes the nine sums of
@@ -1487,7 +1528,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         Gr = v2f{g[0][0], g[1][0]}; Gg = v2f{g[0][1], g[1][1]}; Gb = v2f{g[0][2], g[1][2]};
         suffix = v2f{sfx[0], sfx[1]};
     }
-    const float chik = chi * QK, amax = alpha_max;
+    const float chik = chi * QK, amax = alpha_max, chi_pad = chi * 1.001f + 1e-4f;
     bool alive_any = __any(va || vb);
     uint32_t base = rg.x;
     Candidate cand;
@@ -1499,7 +1540,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     while (alive_any && base < rg.y) {
         uint32_t m8;
         uint64_t ranks;
-        const Staged sg = stage_chunk<MAXQ_BWD>(s, cand, (int)min(rg.y - base, (uint32_t)CHUNK), lane, ox, oy, m8, ranks);
+        const Staged sg = stage_chunk<MAXQ_BWD, BWD_EXACT>(s, cand, (int)min(rg.y - base, (uint32_t)CHUNK), lane, ox, oy, m8, ranks, chi_pad);
         const int n = sg.n, maxc = sg.maxc;
         sb.eid[lane] = cand.id;
         base += (uint32_t)n;
