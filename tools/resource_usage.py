@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Registers, scratch, occupancy and LDS of every kernel:  make -C <csrc> resource-usage-raw 2>&1 | python tools/resource_usage.py"""
+"""Registers, scratch, occupancy and LDS of every kernel:  make -C 3d-..._amd/csrc resource-usage"""
 import re
 import sys
 
