@@ -1091,7 +1091,6 @@ __global__ __launch_bounds__(256) void list_sort_small_kernel(const uint32_t* __
 typedef float v2f __attribute__((ext_vector_type(2)));
 // Exact ellipse / sub-tile test at staging time (subtile_mask_exact), measured on one box: the backward, whose iterations cost
 // 2.5x the forward's, gains (217 -> 207 us); the forward loses (85.6 -> 91.5 us) and keeps the box test.
-constexpr bool BWD_EXACT = true, FWD_EXACT = false;
 constexpr int CHUNK = 64;                            // list entries staged per round (one per lane)
 constexpr int QCAP = CHUNK + 8;                      // queue capacity: the inner loops read entries in pairs
 constexpr uint32_t NULL_OFF = CHUNK * 16;            // byte offset of the null record
@@ -1128,15 +1127,19 @@ static_assert(sizeof(uint16_t) * N_SUB * QCAP == 16 * QCAP, "queue block = QCAP 
 struct Candidate {         // one list entry held by one lane between fetch and staging
     f4 q0, q1, q2;
     uint32_t id;
+    uint32_t saved_mask;   // (backward) the sub-tile mask the forward left for this pair
 };
 
 __device__ __forceinline__ Candidate fetch_candidate(int lane, uint32_t base, uint32_t end, const uint32_t* __restrict__ ids,
-                                                     const Rec64* __restrict__ rec, uint32_t id_max) {
+                                                     const Rec64* __restrict__ rec, uint32_t id_max,
+                                                     const uint8_t* __restrict__ pair_mask = nullptr) {
     Candidate c;
     const uint32_t idx = base + lane;
     c.id = 0;
+    c.saved_mask = 0u;
     c.q0 = c.q1 = c.q2 = f4{0.f, 0.f, 0.f, 0.f};
     if (idx < end) {
+        if (pair_mask) c.saved_mask = pair_mask[idx];
         c.id = min(ids[idx], id_max);                     // never gather outside the record array
         const Rec64* __restrict__ r = rec + c.id;        // one 64-byte line
         c.q0 = r->r0;
@@ -1201,7 +1204,8 @@ __device__ __forceinline__ uint32_t subtile_mask_exact(const Candidate& c, float
     return (A > 0.f && C > 0.f && A * C - B * B > 0.f) ? m : 0xFFu;
 }
 
-template <int MAXQ, bool EXACT = false>
+// MASK: 0 = box test, 1 = box and exact test, 2 = the mask the forward pass saved for this pair (c.saved_mask)
+template <int MAXQ, int MASK = 0>
 __device__ __forceinline__ Staged stage_chunk(RasterLds& s, const Candidate& c, int n, int lane, float ox, float oy, uint32_t& m8,
                                               uint64_t& ranks, float chi_pad = 0.f) {
     __syncthreads();       // previous chunk's LDS reads are done (single-wave block: orders LDS traffic only)
@@ -1212,8 +1216,12 @@ __device__ __forceinline__ Staged stage_chunk(RasterLds& s, const Candidate& c, 
         s.r0[lane] = f4{c.q0.x, c.q0.y, QK * c.q0.z, (2.0f * QK) * c.q0.w};
         s.r1[lane] = f4{QK * c.q1.x, c.q1.y, c.q2.x, c.q2.y};
         s.r2[lane] = f4{c.q2.z, __uint_as_float(c.id), 0.f, 0.f};
-        m8 = subtile_mask(c, ox, oy);
-        if (EXACT) m8 &= subtile_mask_exact(c, ox, oy, chi_pad);
+        if (MASK == 2) {
+            m8 = c.saved_mask;
+        } else {
+            m8 = subtile_mask(c, ox, oy);
+            if (MASK == 1) m8 &= subtile_mask_exact(c, ox, oy, chi_pad);
+        }
     }
     {   // every queue slot -> the null record (QCAP 16-byte pieces)
         const uint32_t nn = NULL_OFF | (NULL_OFF << 16);
@@ -1281,12 +1289,16 @@ __device__ __forceinline__ int launch_priority(uint32_t b, uint32_t grid) {
 }
 
 // (6 waves per SIMD as the compiler leaves it: 76 VGPRs.  Forced to 7 -- 69 VGPRs, no spill -- 90 us against 87.5; to 8: spills, 99 us)
+// SAVE (a backward pass will follow: accum is given): the queues come from the exact ellipse / sub-tile test, which costs this
+// kernel 6 us more than it saves it, and the resulting mask is left per pair (pair_mask, one byte) for the backward, which then
+// needs no test of its own.
+template <bool SAVE>
 __global__ __launch_bounds__(64) void raster_forward_kernel(const uint2* __restrict__ ranges, const uint32_t* __restrict__ ids,
                                                             const Rec64* __restrict__ rec, const uint32_t* __restrict__ order,
                                                             int lists_x, int H, int W, float chi, float alpha_max,
                                                             float alpha_cutoff, float* __restrict__ image,
                                                             float* __restrict__ accum, WaveStats* __restrict__ stats, uint32_t id_max,
-                                                            float* __restrict__ zero_rows, int64_t n_zero_rows) {
+                                                            float* __restrict__ zero_rows, int64_t n_zero_rows, uint8_t* __restrict__ pair_mask) {
     __shared__ RasterLds s;
     const int lane = threadIdx.x;
     if (zero_rows) {        // the coming backward accumulates into grad2d: clear this wave's share now (the kernel is VALU-bound,
@@ -1327,7 +1339,8 @@ __global__ __launch_bounds__(64) void raster_forward_kernel(const uint2* __restr
     while (alive_any && base < rg.y) {
         uint32_t m8;
         uint64_t ranks;
-        const int maxc = stage_chunk<CHUNK, FWD_EXACT>(s, cand, (int)min(rg.y - base, (uint32_t)CHUNK), lane, ox, oy, m8, ranks, chi * 1.001f + 1e-4f).maxc;
+        const int maxc = stage_chunk<CHUNK, SAVE ? 1 : 0>(s, cand, (int)min(rg.y - base, (uint32_t)CHUNK), lane, ox, oy, m8, ranks, chi * 1.001f + 1e-4f).maxc;
+        if (SAVE && base + (uint32_t)lane < rg.y) pair_mask[base + lane] = (uint8_t)m8;     // 64 contiguous bytes per chunk
         base += CHUNK;
         if (base < rg.y) cand = fetch_candidate(lane, base, rg.y, ids, rec, id_max);   // in flight during the loop below
         ++st_chunks;
@@ -1483,7 +1496,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                                                              int lists_x, int H, int W, float chi, float alpha_max,
                                                              float alpha_cutoff, const float* __restrict__ accum,
                                                              const float* __restrict__ gimg, float* __restrict__ grad2d,
-                                                             WaveStats* __restrict__ stats, uint32_t id_max, DetArgs det) {
+                                                             WaveStats* __restrict__ stats, uint32_t id_max, DetArgs det,
+                                                             const uint8_t* __restrict__ pair_mask) {
     __shared__ RasterLdsBwd<DET> sb;
     RasterLds& s = sb.f;
     const int lane = threadIdx.x;
@@ -1528,11 +1542,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         Gr = v2f{g[0][0], g[1][0]}; Gg = v2f{g[0][1], g[1][1]}; Gb = v2f{g[0][2], g[1][2]};
         suffix = v2f{sfx[0], sfx[1]};
     }
-    const float chik = chi * QK, amax = alpha_max, chi_pad = chi * 1.001f + 1e-4f;
+    const float chik = chi * QK, amax = alpha_max;
     bool alive_any = __any(va || vb);
     uint32_t base = rg.x;
     Candidate cand;
-    if (alive_any) cand = fetch_candidate(lane, base, rg.y, ids, rec, id_max);
+    if (alive_any) cand = fetch_candidate(lane, base, rg.y, ids, rec, id_max, pair_mask);
     const int my_g = lane / 9, my_k = lane - 9 * my_g;             // flush: lane i carries sum my_k of the round's row my_g
     const uint16_t* myq = &s.q[grp][0];
     float* const myslot = &sb.slots[grp * MAXQ_BWD * 9 + j];       // + 9 k: where lane j of the group puts sum j of iteration k
@@ -1540,11 +1554,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     while (alive_any && base < rg.y) {
         uint32_t m8;
         uint64_t ranks;
-        const Staged sg = stage_chunk<MAXQ_BWD, BWD_EXACT>(s, cand, (int)min(rg.y - base, (uint32_t)CHUNK), lane, ox, oy, m8, ranks, chi_pad);
+        const Staged sg = stage_chunk<MAXQ_BWD, 2>(s, cand, (int)min(rg.y - base, (uint32_t)CHUNK), lane, ox, oy, m8, ranks);
         const int n = sg.n, maxc = sg.maxc;
         sb.eid[lane] = cand.id;
         base += (uint32_t)n;
-        if (base < rg.y) cand = fetch_candidate(lane, base, rg.y, ids, rec, id_max);   // in flight during the loop below
+        if (base < rg.y) cand = fetch_candidate(lane, base, rg.y, ids, rec, id_max, pair_mask);   // in flight during the loop below
         ++st_chunks;
         st_visited += (uint32_t)maxc;
         int kdone = 0;                       // iterations executed (uniform): slots [0, kdone) of every queue are valid
@@ -1985,9 +1999,16 @@ int64_t gsplat_project_state_bytes(int64_t n, const gsplat_view* v) {
 
 int64_t gsplat_project_scratch_bytes(int64_t n) { (void)n; return up(sizeof(CounterBlock)); }   // the persistent counter block
 
+// bin_state = sorted ids [capacity] (4 B each), then one byte per pair: the sub-tile mask gsplat_rasterize_forward leaves for
+// gsplat_rasterize_backward when it is given `accum`
+inline uint8_t* pair_mask_of(const void* bin_state, int64_t pair_capacity) {
+    return (uint8_t*)bin_state + up((pair_capacity > 0 ? pair_capacity : 1) * 4);
+}
+
 int64_t gsplat_bin_state_bytes(int64_t pair_capacity, const gsplat_view* v) {
     if (!v) return -1;
-    return up((pair_capacity > 0 ? pair_capacity : 1) * 4);                         // sorted ids
+    const int64_t cap = pair_capacity > 0 ? pair_capacity : 1;
+    return up(cap * 4) + up(cap);
 }
 
 int64_t gsplat_bin_scratch_bytes(int64_t pair_capacity, const gsplat_view* v) {
@@ -2103,9 +2124,8 @@ int gsplat_bin(int64_t n, int64_t pair_capacity, const gsplat_view* v, const voi
     return GSPLAT_OK;
 }
 
-int gsplat_rasterize_forward(int64_t n, int64_t n_binned, const gsplat_view* v, const void* project_state, const void* bin_state,
+int gsplat_rasterize_forward(int64_t n, int64_t n_binned, const gsplat_view* v, const void* project_state, void* bin_state,
                              float* image, float* accum, float* grad2d, void* stream_) {
-    (void)n_binned;
     int rc = check_view(v);
     if (rc) return rc;
     if (!project_state || !bin_state || !image) return fail(GSPLAT_ERR_BAD_ARG, "state / image is NULL");
@@ -2113,8 +2133,14 @@ int gsplat_rasterize_forward(int64_t n, int64_t n_binned, const gsplat_view* v, 
     const ViewK vk = make_viewk(*v);
     const int64_t nl = n_lists(v);
     ProjectState ps = carve_project((void*)project_state, n > 0 ? n : 1, nl);
-    hipLaunchKernelGGL(raster_forward_kernel, dim3((unsigned)nl), dim3(64), 0, st, ps.ranges, (const uint32_t*)bin_state, ps.rec,
-                       ps.order, vk.lists_x, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, image, accum, STATS_FWD, (uint32_t)(n > 0 ? n - 1 : 0), grad2d, grad2d ? n : 0);
+    if (accum)      // a backward pass will follow: exact sub-tile masks, saved per pair
+        hipLaunchKernelGGL(raster_forward_kernel<true>, dim3((unsigned)nl), dim3(64), 0, st, ps.ranges, (const uint32_t*)bin_state, ps.rec,
+                           ps.order, vk.lists_x, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, image, accum, STATS_FWD,
+                           (uint32_t)(n > 0 ? n - 1 : 0), grad2d, grad2d ? n : 0, pair_mask_of(bin_state, n_binned));
+    else
+        hipLaunchKernelGGL(raster_forward_kernel<false>, dim3((unsigned)nl), dim3(64), 0, st, ps.ranges, (const uint32_t*)bin_state, ps.rec,
+                           ps.order, vk.lists_x, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, image, accum, STATS_FWD,
+                           (uint32_t)(n > 0 ? n - 1 : 0), grad2d, grad2d ? n : 0, nullptr);
     LAUNCH_CHECK("raster_forward_kernel");
     return GSPLAT_OK;
 }
@@ -2155,7 +2181,7 @@ int gsplat_rasterize_backward(int64_t n, int64_t n_binned, const gsplat_view* v,
     if (!det) {
         hipLaunchKernelGGL(raster_backward_kernel<false>, dim3((unsigned)nl), dim3(64), 0, st, ps.ranges, (const uint32_t*)bin_state, ps.rec,
                            ps.order, vk.lists_x, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, accum, grad_image,
-                           grad2d, STATS_BWD, (uint32_t)(n - 1), DetArgs{});
+                           grad2d, STATS_BWD, (uint32_t)(n - 1), DetArgs{}, pair_mask_of(bin_state, n_binned));
         LAUNCH_CHECK("raster_backward_kernel");
         return GSPLAT_OK;
     }
@@ -2170,7 +2196,8 @@ int gsplat_rasterize_backward(int64_t n, int64_t n_binned, const gsplat_view* v,
     LAUNCH_CHECK("pair_base_kernel");
     hipLaunchKernelGGL(raster_backward_kernel<true>, dim3((unsigned)nl), dim3(64), 0, st, ps.ranges, (const uint32_t*)bin_state, ps.rec,
                        ps.order, vk.lists_x, vk.H, vk.W, vk.chi_clip, vk.alpha_max, vk.alpha_cutoff, accum, grad_image,
-                       grad2d, STATS_BWD, (uint32_t)(n - 1), DetArgs{ps.rect, ps.mask, ps.tiles, ds.pair_base, ds.part, (uint32_t)n_binned});
+                       grad2d, STATS_BWD, (uint32_t)(n - 1), DetArgs{ps.rect, ps.mask, ps.tiles, ds.pair_base, ds.part, (uint32_t)n_binned},
+                       pair_mask_of(bin_state, n_binned));
     LAUNCH_CHECK("raster_backward_kernel<deterministic>");
     hipLaunchKernelGGL(pair_reduce_kernel, dim3(blocks256(n)), dim3(256), 0, st, n, ps.tiles, ds.pair_base, ds.part, (uint32_t)n_binned, grad2d);
     LAUNCH_CHECK("pair_reduce_kernel");

@@ -164,9 +164,12 @@ int gsplat_bin(int64_t n, int64_t pair_capacity, const gsplat_view* v, const voi
 /* F14, F15: per-tile front-to-back compositing.  image[H,W,3] receives clamp(C,0,1); accum[H,W,3]
  * (nullable; required for the backward pass) receives the unclamped C.  grad2d (nullable, [n,16]
  * floats): cleared here for the coming gsplat_rasterize_backward (pass grad2d_zeroed = 1 there), which
- * saves that call a 64-byte-per-Gaussian fill; only worth it when n / lists is small (<= 256).          */
+ * saves that call a 64-byte-per-Gaussian fill; only worth it when n / lists is small (<= 256).
+ * pair_capacity must be the value gsplat_bin was given.  With `accum` (a backward pass will follow) the call
+ * also leaves one byte per pair in bin_state -- which 4 x 4-pixel sub-tiles of its list the Gaussian's ellipse
+ * reaches, by the exact test -- and gsplat_rasterize_backward composites from those.                    */
 int gsplat_rasterize_forward(int64_t n, int64_t pair_capacity, const gsplat_view* v, const void* project_state,
-                             const void* bin_state, float* image, float* accum, float* grad2d, void* stream);
+                             void* bin_state, float* image, float* accum, float* grad2d, void* stream);
 
 /* ---- backward ---------------------------------------------------------------------------------- */
 /* B1: gradient of the compositing w.r.t. the per-Gaussian 2D quantities.  grad2d is [n,16] floats, private to the
