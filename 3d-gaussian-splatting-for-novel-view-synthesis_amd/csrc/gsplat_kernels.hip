@@ -337,13 +337,16 @@ __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const f
     constexpr bool DIRECT = FUSED && COLOUR;
     __shared__ float s_geo[DIRECT ? 4 : sizeof(ProjectLds<FUSED>) / 4];
     ProjectLds<FUSED>& s = *reinterpret_cast<ProjectLds<FUSED>*>(s_geo);
-    __shared__ float s_dc[FUSED && COLOUR ? 64 * 3 : 4];
     __shared__ float s_rest[FUSED && COLOUR ? 64 * 45 : 4];
     const int lane = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * 64, i = row0 + lane;
     GaussIn in;
+    float dc[3] = {0.f, 0.f, 0.f};                           // (DIRECT: the 3 f_dc values with the geometry; 11 520 B of LDS would allow 14
+                                                             //  waves per CU, but the Jacobian variant needs 132 VGPRs: forced to 128 it spills, 94 us against 90)
     if (DIRECT) {                                            // (issued BEFORE the LDS-DMA: vmcnt counts in order)
         if (i < g.n) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dc[k] = g.f_dc[i * 3 + k];
 #pragma unroll
             for (int k = 0; k < 3; ++k) in.p[k] = g.pos[i * 3 + k];
             in.o_raw = g.opacity_raw[i];
@@ -355,10 +358,7 @@ __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const f
     } else {
         stage_geometry<FUSED>(s, g, row0, lane);
     }
-    if (FUSED && COLOUR) {                                   // all inputs of the wave in flight at once
-        stage_rows<3>(s_dc, g.f_dc, row0, g.n, lane);
-        stage_rows<45>(s_rest, g.f_rest, row0, g.n, lane);
-    }
+    if (FUSED && COLOUR) stage_rows<45>(s_rest, g.f_rest, row0, g.n, lane);          // all inputs of the wave in flight at once
     Camera cam;                                              // (derived while the inputs are in flight)
     {
         float m[16];
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const f
     r.vis = o.vis; r.tiles = 0; r.mask = 0u; r.ref_tiles = 0; r.rect = u2{0u, 0u}; r.ref_rect = u2{0u, 0u};
     float kj[12];
     if (FUSED) {
-        if (o.vis == VIS_OK) r = project_finish(in, o, true, ShCoefLds{s_dc + lane * 3, s_rest + lane * 45}, cam, COLOUR, JAC ? kj : nullptr);
+        if (o.vis == VIS_OK) r = project_finish(in, o, true, ShCoefLds{dc, s_rest + lane * 45}, cam, COLOUR, JAC ? kj : nullptr);
     } else if (o.vis == VIS_OK) {
         r = project_finish(in, o, false, ShCoefLds{nullptr, nullptr}, cam);
     }
