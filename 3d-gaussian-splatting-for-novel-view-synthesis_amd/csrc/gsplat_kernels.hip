@@ -332,7 +332,7 @@ __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const f
                                                      Records out, CounterBlock* cb, DevCounts* counts, DevCounts* counts_mapped,
                                                      uint32_t* __restrict__ bin_total, int nb, float* __restrict__ kj_out) {
     // DIRECT (fused inputs with the colour inside): the 44 bytes of geometry per Gaussian are loaded by the lanes themselves (rows
-    // of 3 / 4 floats coalesce well enough) and only the 192 bytes of SH coefficients go through LDS: 12 288 B per wave instead of
+    // of 3 / 4 floats coalesce well enough) and only the 180 bytes of f_rest go through LDS: 11 520 B per wave instead of
     // 15 104 -> 12 waves per CU instead of 10, and the geometry math starts while the coefficients are still arriving.
     constexpr bool DIRECT = FUSED && COLOUR;
     __shared__ float s_geo[DIRECT ? 4 : sizeof(ProjectLds<FUSED>) / 4];
