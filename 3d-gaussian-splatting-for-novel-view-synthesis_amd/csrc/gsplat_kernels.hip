@@ -1216,12 +1216,9 @@ __device__ __forceinline__ Staged stage_chunk(RasterLds& s, const Candidate& c, 
         s.r0[lane] = f4{c.q0.x, c.q0.y, QK * c.q0.z, (2.0f * QK) * c.q0.w};
         s.r1[lane] = f4{QK * c.q1.x, c.q1.y, c.q2.x, c.q2.y};
         s.r2[lane] = f4{c.q2.z, __uint_as_float(c.id), 0.f, 0.f};
-        if (MASK == 2) {
-            m8 = c.saved_mask;
-        } else {
-            m8 = subtile_mask(c, ox, oy);
-            if (MASK == 1) m8 &= subtile_mask_exact(c, ox, oy, chi_pad);
-        }
+        if (MASK == 2) m8 = c.saved_mask;
+        else if (MASK == 1) m8 = subtile_mask_exact(c, ox, oy, chi_pad);      // (conservative by itself: the box test adds nothing)
+        else m8 = subtile_mask(c, ox, oy);
     }
     {   // every queue slot -> the null record (QCAP 16-byte pieces)
         const uint32_t nn = NULL_OFF | (NULL_OFF << 16);
