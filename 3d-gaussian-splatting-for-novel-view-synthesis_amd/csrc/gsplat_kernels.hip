@@ -1169,36 +1169,36 @@ __device__ __forceinline__ uint32_t subtile_mask(const Candidate& c, float ox, f
 // mask (0 beyond the entries taken), ranks = the lane's position in each of its queues (8 bits per sub-tile).
 struct Staged { int n, maxc; };
 // The same question answered exactly: does {q <= chi} (padded by 1e-3 like the list test of the projection, gs_math.h) reach the
-// pixel centres of sub-tile s?  q is convex, so outside the sub-tile its minimum lies on an edge that FACES the centre: at most
-// one vertical and one horizontal edge, each a clamped 1-D quadratic (v_med3).  ~125 instructions per entry for the 8 sub-tiles;
-// removes ~14 % of the (sub-tile, Gaussian) pairs the box test lets through.  Non-PD conics keep the box answer.
+// pixel centres of sub-tile s?  q is convex: its minimum over the sub-tile's rectangle is 0 if the centre is inside, else it lies
+// on an edge that FACES the centre.  With X = the centre's x clamped to the rectangle (0 in centre-relative coordinates if it
+// is inside the x-range, else the nearer vertical edge) the line x = X is that vertical edge -- or, when there is none, a line
+// through the rectangle, whose points are harmless extra candidates -- and the minimum of q along it is a clamped 1-D quadratic
+// (v_med3); the same with Y.  min(qx, qy) is then the exact minimum in every case, the centre-inside case (X = Y = 0 -> 0)
+// included.  ~135 instructions per entry for the 8 sub-tiles; removes ~14 % of the (sub-tile, Gaussian) pairs the box test lets
+// through.  Non-PD conics: every sub-tile.
 __device__ __forceinline__ uint32_t subtile_mask_exact(const Candidate& c, float ox, float oy, float chi_pad) {
     const float u = c.q0.x - ox, v = c.q0.y - oy, A = c.q0.z, B = c.q0.w, C = c.q1.x;
     const float tB_C = -B * __builtin_amdgcn_rcpf(C), tB_A = -B * __builtin_amdgcn_rcpf(A), B2 = 2.0f * B;
     float dx0[4], dx1[4], ax[4], bx[4], tx[4];
-    bool inx[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         dx0[k] = (float)(4 * k) - u; dx1[k] = (float)(4 * k + 3) - u;
-        inx[k] = dx0[k] <= 0.f && dx1[k] >= 0.f;
-        const float X = dx0[k] > 0.f ? dx0[k] : dx1[k];
+        const float X = __builtin_amdgcn_fmed3f(0.0f, dx0[k], dx1[k]);
         ax[k] = A * X * X; bx[k] = B2 * X; tx[k] = tB_C * X;
     }
     uint32_t m = 0u;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const float dy0 = (float)(4 * r) - v, dy1 = (float)(4 * r + 3) - v;
-        const bool iny = dy0 <= 0.f && dy1 >= 0.f;
-        const float Y = dy0 > 0.f ? dy0 : dy1;
+        const float Y = __builtin_amdgcn_fmed3f(0.0f, dy0, dy1);
         const float cy = C * Y * Y, by = B2 * Y, sy = tB_A * Y;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float t = __builtin_amdgcn_fmed3f(tx[k], dy0, dy1);          // minimiser of q on the edge x = X, clamped to the edge
+            const float t = __builtin_amdgcn_fmed3f(tx[k], dy0, dy1);          // minimiser of q on the line x = X, clamped to the rectangle
             const float qx = ax[k] + (bx[k] + C * t) * t;
             const float sc = __builtin_amdgcn_fmed3f(sy, dx0[k], dx1[k]);
             const float qy = cy + (by + A * sc) * sc;
-            const float best = fminf(inx[k] ? 3.0e38f : qx, iny ? 3.0e38f : qy);
-            if ((inx[k] && iny) || !(best > chi_pad)) m |= 1u << (4 * r + k);   // NaN -> touched
+            if (!(fminf(qx, qy) > chi_pad)) m |= 1u << (4 * r + k);             // NaN -> touched
         }
     }
     return (A > 0.f && C > 0.f && A * C - B * B > 0.f) ? m : 0xFFu;
