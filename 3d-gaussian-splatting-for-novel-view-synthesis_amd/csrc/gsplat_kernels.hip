@@ -1758,8 +1758,13 @@ template <bool FUSED, bool JAC = false>
 __global__ __launch_bounds__(64) void project_backward_kernel(gsplat_gaussians g, const Camera* __restrict__ camp, ViewK vk,
                                                               const uint32_t* __restrict__ tiles, const float* __restrict__ grad2d,
                                                               gsplat_gaussian_grads out, bool factored, const float* __restrict__ kj_in) {
-    __shared__ ProjectLds<FUSED> s;
-    __shared__ float s_dc[FUSED ? 64 * 3 : 4];
+    // DIRECT (fused inputs, saved Jacobian): nothing is staged IN (the 44 bytes of geometry are loaded by the lanes), and of the
+    // gradients only the 45 f_rest rows go OUT through LDS (the rows of 1 / 3 / 4 floats are stored by the lanes): 11 520 B per
+    // wave instead of 15 104 -> 14 waves per CU instead of 10.
+    constexpr bool DIRECT = FUSED && JAC;
+    __shared__ float s_geo[DIRECT ? 4 : sizeof(ProjectLds<FUSED>) / 4];
+    ProjectLds<FUSED>& s = *reinterpret_cast<ProjectLds<FUSED>*>(s_geo);
+    __shared__ float s_dc[FUSED && !DIRECT ? 64 * 3 : 4];
     __shared__ float s_rest[FUSED ? 64 * 45 : 4];
     const int lane = threadIdx.x;
     const int64_t row0 = (int64_t)blockIdx.x * 64, i = row0 + lane;
@@ -1768,8 +1773,21 @@ __global__ __launch_bounds__(64) void project_backward_kernel(gsplat_gaussians g
     const bool any_vis = __any(vis);
     float r9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float kj[12];
+    GaussIn in;
     if (any_vis) {
-        stage_geometry<FUSED>(s, g, row0, lane);
+        if (DIRECT) {
+            if (vis) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) in.p[k] = g.pos[i * 3 + k];
+                in.o_raw = g.opacity_raw[i];
+                const f4 q = *reinterpret_cast<const f4*>(g.q_raw + i * 4);
+                in.qr[0] = q.x; in.qr[1] = q.y; in.qr[2] = q.z; in.qr[3] = q.w;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) in.sr[k] = g.scale_raw[i * 3 + k];
+            }
+        } else {
+            stage_geometry<FUSED>(s, g, row0, lane);
+        }
         if (FUSED && !JAC) {
             stage_rows<3>(s_dc, g.f_dc, row0, g.n, lane);
             stage_rows<45>(s_rest, g.f_rest, row0, g.n, lane);
@@ -1786,12 +1804,14 @@ __global__ __launch_bounds__(64) void project_backward_kernel(gsplat_gaussians g
             r9[8] = grad2d[i * 16 + 8];
         }
     }
-    __syncthreads();
+    if (!DIRECT) __syncthreads();
     GradOut go;
+    float gdc[3] = {0.f, 0.f, 0.f};                       // (DIRECT) d L / d f_dc of this lane's Gaussian
+    float* const dc_rows = DIRECT ? gdc : s_dc + lane * 3;
     if (vis) {
-        const GaussIn in = gauss_from_lds<FUSED>(s, lane);
-        go = project_backward_core(in, FUSED, ShCoefLds{s_dc + lane * 3, s_rest + lane * 45},
-                                   ShEmitLds{s_dc + lane * 3, s_rest + lane * 45}, cam, vk, true, r9, true, JAC ? kj : nullptr);
+        if (!DIRECT) in = gauss_from_lds<FUSED>(s, lane);
+        go = project_backward_core(in, FUSED, ShCoefLds{dc_rows, s_rest + lane * 45},
+                                   ShEmitLds{dc_rows, s_rest + lane * 45}, cam, vk, true, r9, true, JAC ? kj : nullptr);
     } else {
 #pragma unroll
         for (int k = 0; k < 3; ++k) { go.p[k] = 0.f; go.sr[k] = 0.f; go.col[k] = 0.f; }
@@ -1802,9 +1822,34 @@ __global__ __launch_bounds__(64) void project_backward_kernel(gsplat_gaussians g
         go.o_raw = 0.f;
         if (FUSED) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) s_dc[lane * 3 + k] = 0.f;
+            for (int k = 0; k < 3; ++k) dc_rows[k] = 0.f;
             for (int k = 0; k < 45; ++k) s_rest[lane * 45 + k] = 0.f;
         }
+    }
+    if (DIRECT) {
+        if (i < g.n) {                                      // every row is written (zeros for a Gaussian that is not visible)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) out.pos[i * 3 + k] = go.p[k];
+            out.opacity_raw[i] = go.o_raw;
+            *reinterpret_cast<f4*>(out.q_raw + i * 4) = f4{go.qr[0], go.qr[1], go.qr[2], go.qr[3]};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) out.scale_raw[i * 3 + k] = go.sr[k];
+            if (factored) {
+                // d L / d f_dc = (d L / d colour logit) * Y0: hand out the 3 logit gradients instead of the 48 SH gradients
+                if (out.color) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) out.color[i * 3 + k] = gdc[k] * (1.0f / GS_K0);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) out.f_dc[i * 3 + k] = gdc[k];
+            }
+        }
+        if (!factored) {
+            __syncthreads();
+            unstage_rows<45>(out.f_rest, s_rest, row0, g.n, lane);
+        }
+        return;
     }
     __syncthreads();      // every lane has read its inputs: the geometry buffers can take the gradients
 #pragma unroll
