@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""How far ahead of the GPU is the host?  Queues K forward+backward steps of the bench scene without waiting for any counter
+(ops.deferred_checks, as bench.py and Trainer.step do) and reports the host's time to QUEUE a step beside the GPU's time to run it
+(diagnostic; needs a GPU).      python tools/host_queue_time.py [config] [steps]"""
+import importlib
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+import bench
+
+PKG = "3d-gaussian-splatting-for-novel-view-synthesis_amd"
+gs = importlib.import_module(PKG)
+ops = importlib.import_module(PKG + ".ops")
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+params, cam = bench.synthetic_scene(cfg)
+dev = torch.device("cuda:0")
+p = {k: v.to(dev).requires_grad_(True) for k, v in params.items()}
+c2w = torch.eye(4, device=dev)
+gimg = torch.rand(cam["H"], cam["W"], 3, device=dev)
+cargs = (cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+
+
+def step():
+    for t in p.values():
+        t.grad = None
+    img = gs.render_gaussians(*[p[k] for k in bench.NAMES], c2w, *cargs)
+    img.backward(gimg)
+
+
+step()                                   # the first frame on a device waits for its counters (sizes the buffers)
+torch.cuda.synchronize()
+for rep in range(3):
+    with ops.deferred_checks() as chk:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            step()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+    chk.verify()
+    print(f"host queues a step in {(t1 - t0) / K * 1e3:.3f} ms; the GPU finishes {(t2 - t1) * 1e3:.1f} ms after the host; "
+          f"{(t2 - t0) / K * 1e3:.3f} ms per step over all")
+
+if len(sys.argv) > 3 and sys.argv[3] == "profile":          # where the host's time goes (cProfile inflates it ~2x)
+    import cProfile
+    import pstats
+    pr = cProfile.Profile()
+    with ops.deferred_checks() as chk:
+        pr.enable()
+        for _ in range(K):
+            step()
+        pr.disable()
+        torch.cuda.synchronize()
+    chk.verify()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(28)
