@@ -68,6 +68,7 @@ class _Workspace:
         self.counters = {}
         self.capacity = {}
         self.slot = {}
+        self.event_pool = {}        # per device: events of frames whose counters have been read, handed out again (get_event(fresh=True))
 
     def get_counter_block(self, device, nbytes):
         """Zeroed once; every gsplat_project call leaves it zeroed again (include/gsplat_mi355x.h)."""
@@ -104,6 +105,10 @@ class _Workspace:
     def get_event(self, device, fresh=False):
         """One reusable event per stream: gsplat_project records it right behind the counters (fresh: an event of its own,
         for a frame whose counters are read later)."""
+        if fresh:
+            pool = self.event_pool.get((device.type, device.index))
+            if pool:
+                return pool.pop()             # (its handle exists, and the frame it belonged to is long done)
         key = self._key(device)
         ev = None if fresh else self.events.get(key)
         if ev is None:
@@ -112,6 +117,11 @@ class _Workspace:
             if not fresh:
                 self.events[key] = ev
         return ev
+
+    def recycle_event(self, device, ev):
+        pool = self.event_pool.setdefault((device.type, device.index), [])
+        if len(pool) < 4 * PINNED_SLOTS:
+            pool.append(ev)
 
     def get_scratch(self, device, nbytes):
         key = self._key(device)
@@ -210,6 +220,7 @@ class DeferredChecks:
             self._offscreen |= _abi.lib().gsplat_classify_counts(C.byref(counts)) == _abi.GSPLAT_SCENE_ALL_OFFSCREEN
             _last_counts = (counts.n_survivors, counts.n_visible, int(counts.n_pairs))
             _last_binned = int(counts.n_binned)
+            _ws.recycle_event(dev, ev)
         del self.pending[:count]
 
     def __enter__(self):
