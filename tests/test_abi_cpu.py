@@ -24,6 +24,21 @@ def test_header_and_python_mirror_agree():
     assert sorted(abi.SIGNATURES) == names
 
 
+def test_header_constants_and_python_mirror_agree():
+    """Every integer #define of the header that the Python host mirrors (flags, status / scene codes, ABI version) has the
+    header's value there; the flag bits of one call are distinct."""
+    txt = open(os.path.join(ROOT, "include", "gsplat_mi355x.h")).read()
+    defs = {k: int(v, 0) for k, v in re.findall(r"^#define\s+(GSPLAT_[A-Z0-9_]+)\s+(-?(?:0x[0-9a-fA-F]+|\d+))\s*$", txt, flags=re.M)}
+    assert defs["GSPLAT_ABI_VERSION"] == abi.ABI_VERSION
+    mirrored = [k for k in defs if hasattr(abi, k)]
+    assert {"GSPLAT_PROJECT_COLOUR_FUSED", "GSPLAT_PROJECT_COUNTS_MAPPED", "GSPLAT_PROJECT_SAVE_SH_JACOBIAN", "GSPLAT_PROJECT_COUNTS_LATE",
+            "GSPLAT_BACKWARD_SH_JACOBIAN"} <= set(mirrored)
+    for k in mirrored:
+        assert getattr(abi, k) == defs[k], k
+    project_flags = [defs[k] for k in defs if k.startswith("GSPLAT_PROJECT_")]
+    assert len(set(project_flags)) == len(project_flags) and all(f & (f - 1) == 0 for f in project_flags)
+
+
 def test_library_exports_every_declared_symbol():
     assert os.path.exists(abi.LIB_PATH), "build the library first: python __graft_entry__.py"
     lib = C.CDLL(abi.LIB_PATH)
@@ -45,9 +60,9 @@ def test_size_queries_are_pure_host_functions():
     v = abi.make_view(1080, 1920, 1100.0, 1100.0, 960.0, 540.0)
     n, p = 1_000_000, 2_720_508
     lists = 120 * 135                                    # 16 x 8-pixel half-tile lists of a 1920 x 1080 image
-    assert lib.gsplat_project_state_bytes(n, C.byref(v)) >= n * 80 + lists * 12
+    assert lib.gsplat_project_state_bytes(n, C.byref(v)) >= n * (84 + 48) + lists * 12      # records + streams + the saved SH Jacobian
     assert lib.gsplat_project_state_bytes(n, None) == -1
-    assert lib.gsplat_bin_state_bytes(p, C.byref(v)) >= p * 4
+    assert lib.gsplat_bin_state_bytes(p, C.byref(v)) >= p * 5                               # sorted ids + one mask byte per pair
     assert lib.gsplat_bin_scratch_bytes(p, C.byref(v)) >= p * 16
     assert lib.gsplat_project_scratch_bytes(n) >= 256 * 64 + 64          # the persistent counter block: 256 shards + the arrival counter
 
