@@ -358,6 +358,7 @@ def main():
     for _ in range(args.warmup):
         step()
     stats = gs.render_stats()
+    p_binned = ops.binned_pairs()            # (list, Gaussian) pairs really binned on this scene (the extras render other scenes later)
     # Untimed calibration pass with an event pair around EVERY library call: per-stage breakdown, and which call dominates.
     # (Each event pair costs ~10 us of stream time, so the timed region below only brackets the dominant call.)
     cal = ops.StageTimer()
@@ -463,7 +464,7 @@ def main():
                                    f"{'forward+backward' if need_grad else 'forward only'}, one camera view per GPU per step"
                                    + ((", gradient exchange over " + ("RCCL" if args.backend == "nccl" else args.backend + " (rehearsal)"))
                                       if world > 1 and need_grad else ""),
-                       "N": N, "V": V, "P": P, "P_binned": gs.ops.binned_pairs() if hasattr(gs, "ops") else None,
+                       "N": N, "V": V, "P": P, "P_binned": p_binned,
                        "tiles": math.ceil(H / 16) * math.ceil(W / 16),
                        "parallelism": f"dp{world} by camera view", "allreduce": info.get(args.exchange),
                        "counts": "waited for in every forward pass" if args.wait_counts else
