@@ -288,21 +288,19 @@ struct Proj {
 };
 
 // Does the region {q <= chi} of a projected Gaussian touch the pixel rectangle [x0, x1] x [y0, y1] (pixel centres,
-// inclusive)?  q is convex: if the centre is outside the rectangle the minimum lies on one of the four edges, where it is
-// a clamped 1-D quadratic.  Conservative (a relative 1e-3 margin on chi dwarfs the fp32 differences with the
-// rasterizer's own evaluation of q), so a "no" means alpha = 0 on every pixel of the rectangle.
+// inclusive)?  q is convex: over the rectangle its minimum is 0 if the centre is inside, else it lies on an edge that faces the
+// centre.  With X = the centre's x clamped to the rectangle (in centre-relative coordinates: 0 if inside the x-range, else the
+// nearer vertical edge) the line x = X is that edge -- or a line through the rectangle, whose points are harmless extra
+// candidates -- and q along it is a clamped 1-D quadratic; the same with Y: min(qx, qy) is the exact minimum in every case.
+// Conservative (a relative 1e-3 margin on chi dwarfs the fp32 differences with the rasterizer's own evaluation of q), so a
+// "no" means alpha = 0 on every pixel of the rectangle.
 GS_HD bool ellipse_touches_rect(const Proj& o, float chi_pad, float r12_22, float r12_11, float x0, float y0, float x1, float y1) {
     const float dx0 = x0 - o.u, dx1 = x1 - o.u, dy0 = y0 - o.v, dy1 = y1 - o.v;
-    const bool in_x = dx0 <= 0.f && dx1 >= 0.f, in_y = dy0 <= 0.f && dy1 >= 0.f;
-    if (in_x && in_y) return true;
-    // Only the edges that FACE the centre can hold the minimum (on an edge the centre is not beyond, q decreases towards the
-    // inside of the rectangle): at most one vertical and one horizontal edge, each a clamped 1-D quadratic (corners included).
-    const float X = dx0 > 0.f ? dx0 : dx1, t = clampf_(r12_22 * X, dy0, dy1);               // minimiser of q along the edge x = X
+    const float X = clampf_(0.f, dx0, dx1), t = clampf_(r12_22 * X, dy0, dy1);               // minimiser of q along the line x = X
     const float qx = o.A11 * X * X + (2.f * o.A12 * X + o.A22 * t) * t;
-    const float Y = dy0 > 0.f ? dy0 : dy1, s_ = clampf_(r12_11 * Y, dx0, dx1);              // ... along the edge y = Y
+    const float Y = clampf_(0.f, dy0, dy1), s_ = clampf_(r12_11 * Y, dx0, dx1);              // ... along the line y = Y
     const float qy = o.A22 * Y * Y + (2.f * o.A12 * Y + o.A11 * s_) * s_;
-    const float best = fminf(in_x ? 3.0e38f : qx, in_y ? 3.0e38f : qy);
-    return !(best > chi_pad);          // NaN -> true
+    return !(fminf(qx, qy) > chi_pad);          // NaN -> true
 }
 
 // Bit k (row-major inside the binned rectangle) = the Gaussian can touch list k.  Rectangles of more than 32 lists are
