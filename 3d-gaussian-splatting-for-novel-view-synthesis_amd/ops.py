@@ -70,18 +70,19 @@ class _Workspace:
         self.slot = {}
         self.event_pool = {}        # per device: events of frames whose counters have been read, handed out again (get_event(fresh=True))
 
-    def get_counter_block(self, device, nbytes):
-        """Zeroed once; every gsplat_project call leaves it zeroed again (include/gsplat_mi355x.h)."""
-        key = self._key(device)
+    def get_counter_block(self, device, nbytes, key=None):
+        """Zeroed once; every gsplat_project call leaves it zeroed again (include/gsplat_mi355x.h).  (`key`: the caller's
+        _key(device), when it has it already -- looking up the current stream is the costliest thing these methods do.)"""
+        key = key or self._key(device)
         buf = self.counters.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.zeros(int(nbytes), dtype=torch.uint8, device=device)
             self.counters[key] = buf
         return buf
 
-    def next_pinned(self, device):
+    def next_pinned(self, device, key=None):
         """A pinned, device-mapped counter block nobody else is using for the next PINNED_SLOTS calls on this stream."""
-        key = self._key(device)
+        key = key or self._key(device)
         ring = self.pinned.get(key)
         if ring is None:
             ring = self.pinned[key] = torch.zeros((PINNED_SLOTS, C.sizeof(_abi.Counts)), dtype=torch.uint8).pin_memory()
@@ -102,14 +103,14 @@ class _Workspace:
     def _key(device):
         return (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
 
-    def get_event(self, device, fresh=False):
+    def get_event(self, device, fresh=False, key=None):
         """One reusable event per stream: gsplat_project records it right behind the counters (fresh: an event of its own,
         for a frame whose counters are read later)."""
         if fresh:
             pool = self.event_pool.get((device.type, device.index))
             if pool:
                 return pool.pop()             # (its handle exists, and the frame it belonged to is long done)
-        key = self._key(device)
+        key = key or self._key(device)
         ev = None if fresh else self.events.get(key)
         if ev is None:
             ev = torch.cuda.Event(enable_timing=False, blocking=False)
@@ -123,8 +124,8 @@ class _Workspace:
         if len(pool) < 4 * PINNED_SLOTS:
             pool.append(ev)
 
-    def get_scratch(self, device, nbytes):
-        key = self._key(device)
+    def get_scratch(self, device, nbytes, key=None):
+        key = key or self._key(device)
         buf = self.scratch.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
@@ -279,7 +280,7 @@ class _Frame:
 
 class _Pending:
     """A forward call between its two halves: projection queued, counters not read yet."""
-    __slots__ = ("frame", "gaussians", "pinned", "ready", "device", "stream", "capacity")
+    __slots__ = ("frame", "gaussians", "pinned", "ready", "device", "stream", "capacity", "key", "st")
 
 
 def _forward_begin(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad=False):
@@ -307,13 +308,15 @@ def _forward_begin(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad=Fal
     pend = _Pending()
     pend.frame, pend.gaussians, pend.device = fr, g, dev
     with torch.cuda.device(dev):
-        pend.stream = torch.cuda.current_stream(dev)
+        pend.stream = torch.cuda.current_stream(dev)                  # looked up ONCE per half of the forward pass
+        pend.key = key = (dev.type, dev.index, pend.stream.cuda_stream)
+        pend.st = C.c_void_p(pend.stream.cuda_stream)
         fr.proj_state = torch.empty(lib.gsplat_project_state_bytes(n, C.byref(view)), dtype=torch.uint8, device=dev)
-        counters = _ws.get_counter_block(dev, lib.gsplat_project_scratch_bytes(n))
+        counters = _ws.get_counter_block(dev, lib.gsplat_project_scratch_bytes(n), key)
         deferred = bool(_deferred_stack) and _ws.pair_capacity(dev) > 0
         pend.capacity = _ws.pair_capacity(dev) if deferred else None
-        pend.pinned = _ws.next_pinned(dev)
-        pend.ready = _ws.get_event(dev, fresh=deferred)
+        pend.pinned = _ws.next_pinned(dev, key)
+        pend.ready = _ws.get_event(dev, fresh=deferred, key=key)
         # the counters go straight into the pinned block (mapped into the device's address space: no copy operation);
         # a frame that will not wait for them evaluates the SH colour inside the projection kernel and lets the first binning
         # kernel total the counters (the projection's waves then retire without waiting for their stores)
@@ -325,7 +328,7 @@ def _forward_begin(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad=Fal
         with _stage("project"):
             _abi.check(lib.gsplat_project(C.byref(g), _p(c2w32), C.byref(view), _p(fr.proj_state), _p(counters),
                                           counters.numel(), C.c_void_p(pend.pinned.data_ptr()), C.c_void_p(pend.ready.cuda_event),
-                                          flags, _stream_ptr(dev)), "gsplat_project")
+                                          flags, pend.st), "gsplat_project")
     return pend, None
 
 
@@ -337,7 +340,7 @@ def _forward_end(pend, need_grad):
     view, n = fr.view, fr.n
     H, W = view.H, view.W
     with torch.cuda.device(dev):
-        st = _stream_ptr(dev)
+        st = pend.st                                 # (the same current stream as in the first half: the caller's contract)
         # the one host wait of the forward pass: the pair count sizes the binning buffers, and the reference's empty /
         # off-screen conventions need the survivor counts.  Only the counters are waited for: the first binning kernel and
         # (fused inputs) the SH colour pass are queued behind them and run during this round trip.
@@ -363,7 +366,7 @@ def _forward_end(pend, need_grad):
                 return image.zero_(), fr, counts
             fr.n_pairs = int(counts.n_binned)        # pairs actually binned (16 x 8 lists); counts.n_pairs = the reference's P
         fr.bin_state = torch.empty(lib.gsplat_bin_state_bytes(fr.n_pairs, C.byref(view)), dtype=torch.uint8, device=dev)
-        scratch = _ws.get_scratch(dev, lib.gsplat_bin_scratch_bytes(fr.n_pairs, C.byref(view)))
+        scratch = _ws.get_scratch(dev, lib.gsplat_bin_scratch_bytes(fr.n_pairs, C.byref(view)), pend.key)
         with _stage("bin"):
             _abi.check(lib.gsplat_bin(n, fr.n_pairs, C.byref(view), _p(fr.proj_state), _p(fr.bin_state), _p(scratch),
                                       scratch.numel(), st), "gsplat_bin")
@@ -431,14 +434,15 @@ def _backward_impl(fr, grad_image):
             return {k: (None if k in ("f_dc", "f_rest") else torch.zeros_like(v)) for k, v in ins.items()}
         return {k: torch.zeros_like(v) for k, v in ins.items()}
     gi = _f32(grad_image, (fr.view.H, fr.view.W, 3), "grad_image")
-    st = _stream_ptr(dev)
+    stream = torch.cuda.current_stream(dev)
+    st = C.c_void_p(stream.cuda_stream)
     with torch.cuda.device(dev):
         zeroed = fr.grad2d is not None
         grad2d = fr.grad2d if zeroed else torch.empty((fr.n, 16), dtype=torch.float32, device=dev)
         fr.grad2d = None                       # a second backward through the same graph must not reuse a dirty buffer
         det = None
         if _deterministic:
-            det = _ws.get_scratch(dev, lib.gsplat_rasterize_backward_scratch_bytes(fr.n, fr.n_pairs))
+            det = _ws.get_scratch(dev, lib.gsplat_rasterize_backward_scratch_bytes(fr.n, fr.n_pairs), (dev.type, dev.index, stream.cuda_stream))
         with _stage("raster_backward"):
             _abi.check(lib.gsplat_rasterize_backward(fr.n, fr.n_pairs, C.byref(fr.view), _p(fr.proj_state), _p(fr.bin_state),
                                                      _p(fr.accum), _p(gi), _p(grad2d), int(zeroed), _p(det),
