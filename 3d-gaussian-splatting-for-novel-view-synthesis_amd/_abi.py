@@ -14,12 +14,17 @@ GSPLAT_OK = 0
 GSPLAT_SCENE_OK = 0
 GSPLAT_SCENE_ALL_CULLED = 10
 GSPLAT_SCENE_ALL_OFFSCREEN = 11
-ABI_VERSION = 4
+ABI_VERSION = 5
 GSPLAT_PROJECT_COLOUR_FUSED = 1
 GSPLAT_PROJECT_COUNTS_MAPPED = 2
 GSPLAT_PROJECT_SAVE_SH_JACOBIAN = 4
 GSPLAT_PROJECT_COUNTS_LATE = 8
 GSPLAT_BACKWARD_SH_JACOBIAN = 1
+GSPLAT_FRAME_BACKWARD = 1
+GSPLAT_FRAME_NO_SH_JACOBIAN = 2
+GSPLAT_BACKWARD_PHASE_RASTER = 2
+GSPLAT_BACKWARD_PHASE_PROJECT = 4
+GSPLAT_BACKWARD_GRAD2D_DIRTY = 8
 
 _F = C.POINTER(C.c_float)
 
@@ -67,6 +72,9 @@ SIGNATURES = {
     "gsplat_rasterize_backward": (_INT, [_I64, _I64, _PV, _VP, _VP, _VP, _VP, _VP, C.c_int32, _VP, _I64, _VP]),
     "gsplat_project_backward": (_INT, [_PG, _VP, _PV, _VP, _VP, _PGG, C.c_int32, _VP]),
     "gsplat_logit_grad": (_INT, [_I64, _PV, _VP, _VP, _VP, _VP]),
+    "gsplat_frame_bytes": (_I64, [_I64, _I64, _PV, C.c_int32]),
+    "gsplat_forward_deferred": (_INT, [_PG, _VP, _PV, _VP, _I64, _I64, _VP, _I64, _VP, _I64, _VP, _VP, _VP, C.c_int32, _VP]),
+    "gsplat_backward": (_INT, [_PG, _VP, _PV, _VP, _I64, _I64, _VP, _PGG, _VP, _VP, _I64, C.c_int32, _VP]),
     "gsplat_sh_accumulate": (_INT, [_I64, C.c_int32, _VP, _VP, _VP, C.c_float, _VP, _VP, _VP]),
     "gsplat_build_sigma": (_INT, [_I64, _VP, _VP, _VP, _VP]),
     "gsplat_build_sigma_backward": (_INT, [_I64, _VP, _VP, _VP, _VP, _VP, _VP]),

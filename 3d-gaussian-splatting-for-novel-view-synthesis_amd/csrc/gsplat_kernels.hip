@@ -1116,12 +1116,15 @@ WaveStats* g_stats_bwd = nullptr;
 
 constexpr float QK = -0.72134752044448170368f;      // -0.5 * log2(e)
 
-struct RasterLds {
+template <int Q>               // Q = slots per queue (the forward kernel: QCAP; the backward kernel, whose queues are capped: fewer)
+struct RasterLdsT {
+    static constexpr int QSLOTS = Q;
     f4 r0[CHUNK + 1];          // u, v, k A11, 2 k A12                    [CHUNK] = the null record
     f4 r1[CHUNK + 1];          // k A22, opacity, r, g
     f4 r2[CHUNK + 1];          // b, Gaussian id (bits), 0, 0
-    uint16_t q[N_SUB][QCAP];   // per sub-tile: record offsets (16 * entry) of the entries that touch it, depth order
+    uint16_t q[N_SUB][Q];      // per sub-tile: record offsets (16 * entry) of the entries that touch it, depth order
 };
+using RasterLds = RasterLdsT<QCAP>;
 static_assert(sizeof(uint16_t) * N_SUB * QCAP == 16 * QCAP, "queue block = QCAP 16-byte pieces");
 
 struct Candidate {         // one list entry held by one lane between fetch and staging
@@ -1205,9 +1208,11 @@ __device__ __forceinline__ uint32_t subtile_mask_exact(const Candidate& c, float
 }
 
 // MASK: 0 = box test, 1 = box and exact test, 2 = the mask the forward pass saved for this pair (c.saved_mask)
-template <int MAXQ, int MASK = 0>
-__device__ __forceinline__ Staged stage_chunk(RasterLds& s, const Candidate& c, int n, int lane, float ox, float oy, uint32_t& m8,
+template <int MAXQ, int MASK = 0, class Lds = RasterLds>
+__device__ __forceinline__ Staged stage_chunk(Lds& s, const Candidate& c, int n, int lane, float ox, float oy, uint32_t& m8,
                                               uint64_t& ranks, float chi_pad = 0.f) {
+    constexpr int QS = Lds::QSLOTS;                         // 16-byte pieces of the queue block
+    static_assert(MAXQ >= CHUNK || MAXQ + 4 <= QS, "a capped queue is read up to MAXQ + 3");
     __syncthreads();       // previous chunk's LDS reads are done (single-wave block: orders LDS traffic only)
     m8 = 0u;
     if (lane == 63) { s.r0[CHUNK] = f4{0.f, 0.f, 0.f, 0.f}; s.r1[CHUNK] = f4{0.f, 0.f, 0.f, 0.f}; s.r2[CHUNK] = f4{0.f, 0.f, 0.f, 0.f}; }
@@ -1223,8 +1228,8 @@ __device__ __forceinline__ Staged stage_chunk(RasterLds& s, const Candidate& c, 
     {   // every queue slot -> the null record (QCAP 16-byte pieces)
         const uint32_t nn = NULL_OFF | (NULL_OFF << 16);
         uint4* qv = reinterpret_cast<uint4*>(&s.q[0][0]);
-        qv[lane] = uint4{nn, nn, nn, nn};
-        if (lane < QCAP - 64) qv[64 + lane] = uint4{nn, nn, nn, nn};
+        if (QS >= 64 || lane < QS) qv[lane] = uint4{nn, nn, nn, nn};
+        if (QS > 64 && lane < QS - 64) qv[64 + lane] = uint4{nn, nn, nn, nn};
     }
     ranks = 0ull;
     if (MAXQ >= CHUNK) {                      // no cap (forward): queue entries written as the ballots come
@@ -1447,8 +1452,11 @@ __device__ __forceinline__ float all_reduce8(float x) {
 #undef DPP_MOV_F32
 
 // backward: longest queue per chunk (sizes the slot block below; see the occupancy note at RasterLdsBwd).
-constexpr int MAXQ_BWD = 24;
-                          // (even: the loop evaluates entries in pairs)
+#ifndef GSPLAT_MAXQ_BWD
+#define GSPLAT_MAXQ_BWD 24
+#endif
+constexpr int MAXQ_BWD = GSPLAT_MAXQ_BWD;                // (even: the loop evaluates entries in pairs)
+constexpr int QSLOTS_BWD = (MAXQ_BWD + 4 + 7) / 8 * 8;   // the loop reads entries k + 2, k + 3 ahead; rows of 16 bytes
 
 // LDS of the backward kernel.  LDS float atomics are slow on this hardware (a ds_add_f32 wave-instruction with 64 lanes cost
 // ~100 LDS cycles here: 230 us of a 450 us kernel), so nothing is accumulated with them: every group writes the nine sums of
@@ -1456,9 +1464,10 @@ constexpr int MAXQ_BWD = 24;
 // was queued in (it knows its rank in every queue) and leaves the row in `acc` for the flush.
 // LDS per wave decides the occupancy here (12.8 KB -> 12 waves per CU): the chunk's rows `acc` [entry][9] reuse the record
 // arrays, which are dead once the chunk's loop is over (the null record is rewritten by every stage_chunk).
+using RasterLdsB = RasterLdsT<QSLOTS_BWD>;
 template <bool DET>
 struct RasterLdsBwd {
-    RasterLds f;
+    RasterLdsB f;
     float slots[N_SUB * MAXQ_BWD * 9];   // [sub-tile][queue position][9 sums]
     uint32_t eid[CHUNK];                 // Gaussian id of every entry of the chunk
     uint32_t eslot[DET ? CHUNK : 1];     // (deterministic mode) the row's slot
@@ -1466,7 +1475,10 @@ struct RasterLdsBwd {
 // LDS is handed out in coarse pieces (1280 B by the look of it): at 12 848 B per wave 11 waves were resident per CU (measured with
 // tools/raster_stats.py: 2816 waves), at 12 608 B twelve (231 -> 221 us), at 11 456 B and 128 VGPRs fourteen (214 us); sixteen
 // (queue cap 18: 10 KB) lose more to chunks cut short than they gain (228 us).
-static_assert(sizeof(RasterLdsBwd<false>) <= 11520, "the backward kernel's LDS per wave decides its occupancy");
+#ifndef GSPLAT_BWD_LDS_MAX
+#define GSPLAT_BWD_LDS_MAX 11520
+#endif
+static_assert(sizeof(RasterLdsBwd<false>) <= GSPLAT_BWD_LDS_MAX, "the backward kernel's LDS per wave decides its occupancy");
 static_assert(sizeof(f4) * 3 * (CHUNK + 1) >= sizeof(float) * CHUNK * 9, "acc must fit into the record arrays");
 
 // K7: same traversal as K6 (identical T_i and alive decisions).  For pixel p and Gaussian i:
@@ -1496,7 +1508,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                                                              WaveStats* __restrict__ stats, uint32_t id_max, DetArgs det,
                                                              const uint8_t* __restrict__ pair_mask) {
     __shared__ RasterLdsBwd<DET> sb;
-    RasterLds& s = sb.f;
+    RasterLdsB& s = sb.f;
     const int lane = threadIdx.x;
     const uint32_t list = order[blockIdx.x];
     const uint2 rg = ranges[list];
@@ -1551,7 +1563,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     while (alive_any && base < rg.y) {
         uint32_t m8;
         uint64_t ranks;
-        const Staged sg = stage_chunk<MAXQ_BWD, 2>(s, cand, (int)min(rg.y - base, (uint32_t)CHUNK), lane, ox, oy, m8, ranks);
+        const Staged sg = stage_chunk<MAXQ_BWD, 2, RasterLdsB>(s, cand, (int)min(rg.y - base, (uint32_t)CHUNK), lane, ox, oy, m8, ranks);
         const int n = sg.n, maxc = sg.maxc;
         sb.eid[lane] = cand.id;
         base += (uint32_t)n;
@@ -2187,9 +2199,10 @@ int gsplat_rasterize_forward(int64_t n, int64_t n_binned, const gsplat_view* v, 
     return GSPLAT_OK;
 }
 
-namespace {
+// (helpers inside the extern "C" block must be `static`: an anonymous namespace does not stop a function with C linkage from
+//  being exported, and the product library exports nothing but the gsplat_* entry points -- tests/test_abi_cpu.py)
 struct DetScratch { float* part; uint32_t* pair_base; uint32_t* block_sum; int64_t bytes; };
-DetScratch carve_det(void* base, int64_t n, int64_t capacity) {
+static DetScratch carve_det(void* base, int64_t n, int64_t capacity) {
     DetScratch d;
     char* p = (char*)base;
     int64_t o = 0;
@@ -2199,7 +2212,6 @@ DetScratch carve_det(void* base, int64_t n, int64_t capacity) {
     d.bytes = o;
     return d;
 }
-}  // namespace
 
 int64_t gsplat_rasterize_backward_scratch_bytes(int64_t n, int64_t pair_capacity) { return carve_det(nullptr, n, pair_capacity).bytes; }
 
@@ -2270,6 +2282,79 @@ int gsplat_project_backward(const gsplat_gaussians* g, const float* c2w, const g
     else
         hipLaunchKernelGGL((project_backward_kernel<false, false>), dim3(blocks64(g->n)), dim3(64), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out, false, nullptr);
     LAUNCH_CHECK("project_backward_kernel");
+    return GSPLAT_OK;
+}
+
+// ---- one call per direction (include/gsplat_mi355x.h: "composite entries") ----------------------------------------------
+// The frame arena: project_state | bin_state | accum | grad2d, each part 256-byte aligned.  Host-side arithmetic only.
+struct FrameParts { int64_t project_state, bin_state, accum, grad2d, total; };
+static FrameParts frame_parts(int64_t n, int64_t pair_capacity, const gsplat_view* v, int32_t flags) {
+    FrameParts f;
+    int64_t o = 0;
+    f.project_state = o; o += up(carve_project(nullptr, n > 0 ? n : 1, n_lists(v)).bytes);
+    f.bin_state = o; o += up(gsplat_bin_state_bytes(pair_capacity, v));
+    f.accum = f.grad2d = -1;
+    if (flags & GSPLAT_FRAME_BACKWARD) {
+        f.accum = o; o += up((int64_t)v->H * v->W * 3 * (int64_t)sizeof(float));
+        f.grad2d = o; o += up((n > 0 ? n : 1) * 16 * (int64_t)sizeof(float));
+    }
+    f.total = o;
+    return f;
+}
+// the forward pass clears grad2d on the side unless there are so few lists that a wave's share would be long
+static bool forward_clears_grad2d(int64_t n, const gsplat_view* v) { return n <= 256 * n_lists(v); }
+
+int64_t gsplat_frame_bytes(int64_t n, int64_t pair_capacity, const gsplat_view* v, int32_t flags) {
+    if (!v || v->H <= 0 || v->W <= 0 || n < 0 || pair_capacity < 0) return -1;
+    return frame_parts(n, pair_capacity, v, flags).total;
+}
+
+int gsplat_forward_deferred(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, void* frame, int64_t frame_bytes,
+                            int64_t pair_capacity, void* counters, int64_t counters_bytes, void* bin_scratch, int64_t bin_scratch_bytes,
+                            gsplat_counts* counts_host, void* counts_event, float* image, int32_t flags, void* stream_) {
+    if (!g || !v) return fail(GSPLAT_ERR_BAD_ARG, "gaussians / view is NULL");
+    int rc = check_view(v);
+    if (rc) return rc;
+    if (!frame || !image) return fail(GSPLAT_ERR_BAD_ARG, "frame / image is NULL");
+    if (reinterpret_cast<uintptr_t>(frame) & 255u) return fail(GSPLAT_ERR_BAD_ARG, "frame must be 256-byte aligned");
+    if (pair_capacity < 1) return fail(GSPLAT_ERR_BAD_ARG, "pair_capacity must be positive (a capacity kept from earlier frames)");
+    const FrameParts f = frame_parts(g->n, pair_capacity, v, flags);
+    if (f.total > frame_bytes) return fail(GSPLAT_ERR_WORKSPACE, "frame arena too small (gsplat_frame_bytes)");
+    char* base = (char*)frame;
+    const bool bwd = (flags & GSPLAT_FRAME_BACKWARD) != 0;
+    const bool fused = g->scale_raw != nullptr;
+    int32_t pf = GSPLAT_PROJECT_COLOUR_FUSED | GSPLAT_PROJECT_COUNTS_LATE | (counts_host ? GSPLAT_PROJECT_COUNTS_MAPPED : 0);
+    if (bwd && fused && !(flags & GSPLAT_FRAME_NO_SH_JACOBIAN)) pf |= GSPLAT_PROJECT_SAVE_SH_JACOBIAN;
+    if ((rc = gsplat_project(g, c2w, v, base + f.project_state, counters, counters_bytes, counts_host, counts_event, pf, stream_))) return rc;
+    if ((rc = gsplat_bin(g->n, pair_capacity, v, base + f.project_state, base + f.bin_state, bin_scratch, bin_scratch_bytes, stream_))) return rc;
+    float* accum = bwd ? (float*)(base + f.accum) : nullptr;
+    float* grad2d = bwd && forward_clears_grad2d(g->n, v) ? (float*)(base + f.grad2d) : nullptr;
+    return gsplat_rasterize_forward(g->n, pair_capacity, v, base + f.project_state, base + f.bin_state, image, accum, grad2d, stream_);
+}
+
+int gsplat_backward(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, void* frame, int64_t frame_bytes,
+                    int64_t pair_capacity, const float* grad_image, const gsplat_gaussian_grads* out, float* grad_logit,
+                    void* det_scratch, int64_t det_scratch_bytes, int32_t flags, void* stream_) {
+    if (!g || !v) return fail(GSPLAT_ERR_BAD_ARG, "gaussians / view is NULL");
+    int rc = check_view(v);
+    if (rc) return rc;
+    if (!frame) return fail(GSPLAT_ERR_BAD_ARG, "frame is NULL");
+    const FrameParts f = frame_parts(g->n, pair_capacity, v, GSPLAT_FRAME_BACKWARD);
+    if (f.total > frame_bytes) return fail(GSPLAT_ERR_WORKSPACE, "frame arena too small: was it made with GSPLAT_FRAME_BACKWARD?");
+    char* base = (char*)frame;
+    float* grad2d = (float*)(base + f.grad2d);
+    const bool both = !(flags & (GSPLAT_BACKWARD_PHASE_RASTER | GSPLAT_BACKWARD_PHASE_PROJECT));
+    if (both || (flags & GSPLAT_BACKWARD_PHASE_RASTER)) {
+        if (!grad_image) return fail(GSPLAT_ERR_BAD_ARG, "grad_image is NULL");
+        const int32_t zeroed = forward_clears_grad2d(g->n, v) && !(flags & GSPLAT_BACKWARD_GRAD2D_DIRTY);
+        if ((rc = gsplat_rasterize_backward(g->n, pair_capacity, v, base + f.project_state, base + f.bin_state, (const float*)(base + f.accum),
+                                            grad_image, grad2d, zeroed, det_scratch, det_scratch_bytes, stream_))) return rc;
+        if (grad_logit && (rc = gsplat_logit_grad(g->n, v, base + f.project_state, grad2d, grad_logit, stream_))) return rc;
+    }
+    if (both || (flags & GSPLAT_BACKWARD_PHASE_PROJECT)) {
+        if (!out) return fail(GSPLAT_ERR_BAD_ARG, "grads is NULL");
+        if ((rc = gsplat_project_backward(g, c2w, v, base + f.project_state, grad2d, out, flags & GSPLAT_BACKWARD_SH_JACOBIAN, stream_))) return rc;
+    }
     return GSPLAT_OK;
 }
 

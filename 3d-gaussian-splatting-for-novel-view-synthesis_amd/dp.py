@@ -56,6 +56,23 @@ def any_rank(flag, group=None, device=None):
     return int(t.item())
 
 
+STATUS_OK, STATUS_REDO, STATUS_OFFSCREEN, STATUS_ERROR = 0, 1, 2, 3
+
+
+def agree_status(code, group=None, device=None):
+    """The worst status over the ranks (ONE tiny all-reduce, MAX): 0 = every rank's pass is good, 1 = some rank's pair buffers
+    overflowed (all repeat the pass), 2 = some rank's view had survivors but nothing on screen (all raise the reference's
+    Exception), 3 = some rank failed otherwise (all raise).  Every rank must call it once per pass, whatever happened to it
+    locally: a rank that leaves the step by an exception before this point would leave the others waiting in a collective."""
+    code = int(code)
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return code
+    on_gpu = dist.get_backend(group) != "gloo"
+    t = torch.tensor([code], dtype=torch.int32, device=device if on_gpu and device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
+
+
 def _big_and_small(grads):
     """Split a list of gradient tensors into the largest (sent in place) and the rest (flattened together)."""
     order = sorted(range(len(grads)), key=lambda i: grads[i].numel(), reverse=True)
@@ -191,11 +208,18 @@ class FactoredExchange:
         self._early = []                         # (gathered logits, gathered eyes, pending collectives) per local view
         self._accumulate = accumulate
         self._force = force_collectives          # tests: issue the collectives even in a one-rank group
+        self.n_added = 0                         # views handed in by the render backward (Trainer.step checks it against its views)
 
-    def owns(self, inputs):
-        """Is this render differentiating the parameters this exchange was built for (same f_dc / f_rest storage)?"""
+    def owns(self, inputs, src_ptrs=None):
+        """Is this render differentiating the parameters this exchange was built for (same f_dc / f_rest storage)?
+        src_ptrs: the addresses of the caller's own f_dc / f_rest tensors, BEFORE the host's dtype / layout conversion (a model
+        whose SH tensors are not fp32-contiguous is converted by the render; comparing the converted copies would silently
+        send its frames down the ordinary path, and the replicas would diverge)."""
         try:
-            return all(inputs[k].data_ptr() == self.params[k].data_ptr() for k in ("f_dc", "f_rest"))
+            mine = (self.params["f_dc"].data_ptr(), self.params["f_rest"].data_ptr())
+            if src_ptrs is not None:
+                return tuple(src_ptrs) == mine
+            return (inputs["f_dc"].data_ptr(), inputs["f_rest"].data_ptr()) == mine
         except (KeyError, AttributeError):
             return False
 
@@ -206,6 +230,7 @@ class FactoredExchange:
         """Called by the render backward with one view's logit gradients BEFORE it launches the projection backward: with
         equal view counts the all-gather of this view starts here (async) and overlaps that kernel."""
         eye = eye.detach().to(torch.float32).contiguous()
+        self.n_added += 1
         if self._distributed() and self.equal_views and not (dist.get_backend(self.group) == "gloo" and grad_logit.is_cuda):
             world = dist.get_world_size(self.group)
             n = grad_logit.shape[0]             # outputs in the concatenated form (every backend takes it), viewed per rank below
@@ -228,12 +253,22 @@ class FactoredExchange:
         ops.set_sh_gradient_sink(None)
         return False
 
+    def pad_views(self, expected):
+        """A rank whose pass stopped early (an exception in one of its renders) has issued fewer per-view collectives than its
+        peers: issue the missing ones on zeros, so that the NEXT collective of every rank -- the status agreement -- lines up.
+        (Only the view-by-view gathers of add() are collectives; with unequal view counts nothing is exchanged before finish().)"""
+        n = self.params["pos"].shape[0]
+        dev = self.params["pos"].device
+        while self.n_added < int(expected):
+            self.add(torch.zeros((n, 3), dtype=torch.float32, device=dev), torch.zeros(3, dtype=torch.float32, device=dev))
+
     def abandon(self):
         """Drop what was collected (the pass is being repeated): collectives already in flight are waited for, nothing is kept."""
         for _, _, works in self._early:
             for w in works[:2]:
                 w.wait()
         self.logits, self.eyes, self._early = [], [], []
+        self.n_added = 0
 
     def finish(self):
         p = self.params
@@ -285,3 +320,4 @@ class FactoredExchange:
             if self.world_views != 1:
                 base.mul_(1.0 / self.world_views)
         self.logits, self.eyes, self._early = [], [], []
+        self.n_added = 0

@@ -14,6 +14,7 @@ PyTorch is plumbing here (device memory, streams, autograd bookkeeping); all ari
 There is no CPU path: CPU tensors, or a missing library, raise.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 import torch
@@ -35,6 +36,10 @@ def _f32(t, shape, name):
     """Detached, contiguous fp32 view/copy of a tensor argument (reference tensors are already fp32 contiguous)."""
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor")
+    # (the usual case first: an fp32, contiguous, aligned GPU tensor of the right shape is used as it stands -- only its
+    #  address travels to the library, autograd never sees it)
+    if t.dtype is torch.float32 and t.is_cuda and t.shape == shape and t.is_contiguous() and not t.data_ptr() % 16:
+        return t
     if not t.is_cuda:
         raise RuntimeError(f"{name} is on {t.device}: the MI355X rasterizer needs GPU tensors (there is no CPU fallback)")
     if tuple(t.shape) != tuple(shape):
@@ -56,10 +61,16 @@ class PairCapacityExceeded(RuntimeError):
 PINNED_SLOTS = 256      # counter blocks in flight per (device, stream) before one is reused
 
 
+def capacity_key(device, view, n):
+    """Pair capacities are kept per (device, image size, power-of-two bucket of the Gaussian count): one large scene does not
+    make every later frame of a small one allocate, launch over and (deterministic mode) clear its buffers."""
+    return (device.type, device.index, view.H, view.W, max(int(n), 1).bit_length())
+
+
 class _Workspace:
     """Grow-only scratch buffers, the persistent counter block of gsplat_project, a ring of pinned counter blocks and one
     event per (device, stream): calls on different streams never share them (scratch is dead after each call, in stream
-    order).  `capacity`: per device, the largest pair count seen x 1.25 (sizes the buffers of frames that do not wait)."""
+    order).  `capacity`: per capacity_key(), the largest pair count seen x 1.25 (sizes the buffers of frames that do not wait)."""
 
     def __init__(self):
         self.scratch = {}
@@ -68,7 +79,9 @@ class _Workspace:
         self.counters = {}
         self.capacity = {}
         self.slot = {}
+        self.owners = {}            # per (device, stream): slot -> weak reference to the DeferredChecks that still has to read it
         self.event_pool = {}        # per device: events of frames whose counters have been read, handed out again (get_event(fresh=True))
+        self.sizes = {}             # (n, capacity, H, W, flags) -> (frame bytes, bin scratch bytes): host arithmetic, cached
 
     def get_counter_block(self, device, nbytes, key=None):
         """Zeroed once; every gsplat_project call leaves it zeroed again (include/gsplat_mi355x.h).  (`key`: the caller's
@@ -80,24 +93,37 @@ class _Workspace:
             self.counters[key] = buf
         return buf
 
-    def next_pinned(self, device, key=None):
-        """A pinned, device-mapped counter block nobody else is using for the next PINNED_SLOTS calls on this stream."""
+    def next_pinned(self, device, key=None, owner=None):
+        """A pinned, device-mapped counter block nobody else is using.  A slot whose last frame still waits to be looked at by
+        its DeferredChecks (a block left without verify(), or a very long one) is read by that owner first -- the frame
+        finished long ago -- so a ring that comes round never hands out a block somebody still has to read."""
         key = key or self._key(device)
         ring = self.pinned.get(key)
         if ring is None:
             ring = self.pinned[key] = torch.zeros((PINNED_SLOTS, C.sizeof(_abi.Counts)), dtype=torch.uint8).pin_memory()
+            self.owners[key] = {}
         i = self.slot.get(key, 0)
         self.slot[key] = (i + 1) % PINNED_SLOTS
-        return ring[i]
+        owners = self.owners[key]
+        ref = owners.pop(i, None)
+        if ref is not None:
+            prev = ref()
+            if prev is not None:
+                prev._release_slot(key, i)
+        if owner is not None:
+            owners[i] = weakref.ref(owner)
+        return ring[i], i
 
-    def note_pairs(self, device, n_binned):
-        key = (device.type, device.index)
+    def note_pairs(self, ckey, n_binned):
         want = int(n_binned * 1.25) + 4096
-        if want > self.capacity.get(key, 0):
-            self.capacity[key] = want
+        if want > self.capacity.get(ckey, 0):
+            self.capacity[ckey] = want
 
-    def pair_capacity(self, device):
-        return self.capacity.get((device.type, device.index), 0)
+    def pair_capacity(self, ckey):
+        return self.capacity.get(ckey, 0)
+
+    def reset_pair_capacity(self):
+        self.capacity.clear()
 
     @staticmethod
     def _key(device):
@@ -132,6 +158,21 @@ class _Workspace:
             self.scratch[key] = buf
         return buf
 
+    def frame_sizes(self, lib, n, capacity, view, flags):
+        k = (n, capacity, view.H, view.W, flags)
+        got = self.sizes.get(k)
+        if got is None:
+            if len(self.sizes) > 4096:
+                self.sizes.clear()
+            got = self.sizes[k] = (lib.gsplat_frame_bytes(n, capacity, C.byref(view), flags),
+                                   lib.gsplat_bin_scratch_bytes(capacity, C.byref(view)))
+        return got
+
+
+def reset_pair_capacity():
+    """Forget the pair capacities kept from earlier frames (a new scene, a new Trainer): the next frame of every (device, image
+    size, Gaussian-count bucket) waits for its own count again."""
+    _ws.reset_pair_capacity()
 
 
 _ws = _Workspace()
@@ -193,43 +234,64 @@ class DeferredChecks:
         chk.verify()                                                        # ONE wait, then every frame's checks
 
     Inside the block a render sizes its pair buffers from the capacity kept from earlier frames (x 1.25 of the largest
-    count seen on the device) instead of waiting for its own count, and the SH colour is evaluated inside the projection
-    kernel (one pass over the inputs).  What the reference decides from the counts is decided in verify(): survivors but
-    none on screen -> the same Exception("All projected points are off-screen"), now raised there; no survivor -> the frame
-    was a zero image with zero gradients anyway.  A frame with more pairs than the capacity raises PairCapacityExceeded
-    (capacity raised; render the block again: its results are invalid).  The first render on a device (no capacity known
-    yet) waits like an ordinary one."""
+    count seen for that image size and Gaussian-count bucket) instead of waiting for its own count, and the SH colour is
+    evaluated inside the projection kernel (one pass over the inputs).  What the reference decides from the counts is decided
+    in verify(): survivors but none on screen -> the same Exception("All projected points are off-screen"), now raised there; no
+    survivor -> the frame was a zero image with zero gradients anyway.  A frame with more pairs than the capacity raises
+    PairCapacityExceeded (capacity raised; render the block again: its results are invalid).  The first render of a size on a
+    device (no capacity known yet) waits like an ordinary one.
+
+    A block that is left by an exception has its frames' counters read then and there (nothing is raised on top of the exception
+    in flight); one that is simply never verified keeps its findings, and its pinned counter blocks are read before the ring
+    hands them to another frame (_Workspace.next_pinned): no block is ever reused unread."""
 
     def __init__(self):
-        self.pending = []          # (pinned counter block, event, capacity, device)
+        self.pending = []          # [pinned counter block, event, capacity, device, capacity key, (ring key, slot)]
         self.counts = []
         self._overflow = self._offscreen = False
 
-    def add(self, pinned, event, capacity, device):
-        self.pending.append((pinned, event, capacity, device))
+    def add(self, pinned, event, capacity, device, ckey, slot):
+        self.pending.append((pinned, event, capacity, device, ckey, slot))
         if len(self.pending) >= PINNED_SLOTS // 2:           # long sequences: look at the oldest frames before their pinned
             self._drain(len(self.pending) // 2)              # counter blocks come round again (they finished long ago)
 
     def _drain(self, count):
         global _last_counts, _last_binned
-        for pinned, ev, cap, dev in self.pending[:count]:
+        for pinned, ev, cap, dev, ckey, slot in self.pending[:count]:
             ev.synchronize()
             counts = _abi.Counts.from_buffer_copy(pinned.numpy().tobytes())
             self.counts.append(counts)
-            _ws.note_pairs(dev, counts.n_binned)
+            _ws.note_pairs(ckey, counts.n_binned)
             self._overflow |= cap is not None and counts.n_binned > cap
             self._offscreen |= _abi.lib().gsplat_classify_counts(C.byref(counts)) == _abi.GSPLAT_SCENE_ALL_OFFSCREEN
             _last_counts = (counts.n_survivors, counts.n_visible, int(counts.n_pairs))
             _last_binned = int(counts.n_binned)
             _ws.recycle_event(dev, ev)
+            owners = _ws.owners.get(slot[0])
+            if owners is not None:
+                ref = owners.get(slot[1])
+                if ref is not None and ref() is self:
+                    del owners[slot[1]]
         del self.pending[:count]
+
+    def _release_slot(self, ring_key, index):
+        """The ring is about to hand slot `index` to another frame: read everything up to the frame that holds it."""
+        for k, entry in enumerate(self.pending):
+            if entry[5] == (ring_key, index):
+                self._drain(k + 1)
+                return
 
     def __enter__(self):
         _deferred_stack.append(self)
         return self
 
-    def __exit__(self, *exc):
+    def __exit__(self, exc_type, exc, tb):
         _deferred_stack.remove(self)
+        if exc_type is not None and self.pending:           # nobody will call verify(): read the counters now, raise nothing
+            try:
+                self._drain(len(self.pending))
+            except Exception:                                # (a device error while draining must not mask the exception in flight)
+                self.pending = []
         return False
 
     def verify(self):
@@ -245,6 +307,7 @@ class DeferredChecks:
 
 _deferred_stack = []
 forward_modes = {"waited": 0, "deferred": 0}     # forward passes that waited for their counters / that did not (diagnostics, tests)
+composite_calls = {"forward": 0, "backward": 0}  # passes queued through ONE library call (gsplat_forward_deferred / gsplat_backward)
 
 
 def deferred_checks():
@@ -271,65 +334,116 @@ def _make_gaussians(n, pos, opacity_raw, color=None, sigma=None, scale_raw=None,
 
 
 _sh_jacobian = True      # tests / ablations switch it off: the backward then reads the SH coefficients again (same gradients)
+_composite = True        # tests / ablations switch it off: a deferred frame then goes through the separate library calls
 
 
 class _Frame:
-    """Everything the backward pass needs from one forward call."""
-    __slots__ = ("view", "n", "n_pairs", "proj_state", "bin_state", "accum", "fused", "inputs", "c2w", "empty", "grad2d", "sh_jacobian")
+    """Everything the backward pass needs from one forward call.  A frame queued by gsplat_forward_deferred keeps ONE arena
+    (project_state | bin_state | accum | grad2d, carved by the library); one that went through the separate calls keeps them
+    as separate buffers."""
+    __slots__ = ("view", "n", "n_pairs", "proj_state", "bin_state", "accum", "fused", "inputs", "c2w", "empty", "grad2d", "sh_jacobian",
+                 "arena", "gaussians", "dirty", "src_ptrs")
 
 
 class _Pending:
     """A forward call between its two halves: projection queued, counters not read yet."""
-    __slots__ = ("frame", "gaussians", "pinned", "ready", "device", "stream", "capacity", "key", "st")
+    __slots__ = ("frame", "gaussians", "pinned", "ready", "device", "stream", "capacity", "key", "st", "ckey", "slot")
 
 
-def _forward_begin(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad=False):
-    """First half of the forward pass: everything up to (not including) the host's wait for the counters.  Returns
-    (pending, None), or (None, result) when there is nothing to wait for (zero Gaussians).  Inside a deferred_checks()
-    block (and once a pair capacity is known for the device) the second half will not wait: pending.capacity is set."""
-    lib = _abi.lib()
-    dev = pos.device
-    n = pos.shape[0]
+def _convert_inputs(fused, n, pos, opacity_raw, c2w, a, b, c, d):
     pos32 = _f32(pos, (n, 3), "pos")
-    opa32 = _f32(opacity_raw.reshape(-1), (n,), "opacity_raw")
+    opa32 = _f32(opacity_raw if opacity_raw.dim() == 1 else opacity_raw.reshape(-1), (n,), "opacity_raw")
     c2w32 = _f32(c2w, (4, 4), "c2w")
     if fused:
         ins = dict(scale_raw=_f32(a, (n, 3), "scale_raw"), q_raw=_f32(b, (n, 4), "q_raw"), f_dc=_f32(c, (n, 3), "f_dc"),
                    f_rest=_f32(d, (n, 45), "f_rest"))
     else:
         ins = dict(color=_f32(a, (n, 3), "color"), sigma=_f32(b, (n, 3, 3), "sigma"))
-    g = _make_gaussians(n, pos32, opa32, **ins)
+    return pos32, opa32, c2w32, ins
+
+
+def _new_frame(fused, view, n, pos32, opa32, c2w32, ins, c, d):
     fr = _Frame()
     fr.view, fr.n, fr.fused, fr.c2w, fr.empty, fr.sh_jacobian = view, n, fused, c2w32, False, False
     fr.inputs = dict(pos=pos32, opacity_raw=opa32, **ins)
+    fr.arena = fr.gaussians = fr.proj_state = fr.bin_state = fr.accum = fr.grad2d = None
+    fr.dirty = False
+    # the caller's own SH tensors (before any dtype / layout conversion): what dp.FactoredExchange.owns() compares
+    fr.src_ptrs = (c.data_ptr(), d.data_ptr()) if fused else None
+    return fr
+
+
+def _forward_begin(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad=False):
+    """First half of the forward pass: everything up to (not including) the host's wait for the counters.  Returns
+    (pending, None), or (None, result) when nothing is left to do: zero Gaussians, or -- inside a deferred_checks() block once a
+    pair capacity is known for this image size -- the whole forward pass was queued by ONE library call
+    (gsplat_forward_deferred) and the result is there."""
+    lib = _abi.lib()
+    dev = pos.device
+    n = pos.shape[0]
+    pos32, opa32, c2w32, ins = _convert_inputs(fused, n, pos, opacity_raw, c2w, a, b, c, d)
+    fr = _new_frame(fused, view, n, pos32, opa32, c2w32, ins, c, d)
     if n == 0:      # nothing survives by construction: the reference returns the zero image (render.py:109-112)
-        fr.empty, fr.proj_state = True, None
+        fr.empty = True
         return None, (torch.zeros((view.H, view.W, 3), dtype=torch.float32, device=dev), fr, _abi.Counts(0, 0, 0, 0, 0, 0))
+    g = _make_gaussians(n, pos32, opa32, **ins)
+    ckey = capacity_key(dev, view, n)
+    capacity = _ws.pair_capacity(ckey) if _deferred_stack else 0
+    deferred = capacity > 0
+    if torch.cuda.current_device() != dev.index:
+        torch.cuda.set_device(dev)            # (a context manager per call costs more than the call: the one-process-per-GPU host never switches)
+    stream = torch.cuda.current_stream(dev)                       # looked up ONCE per forward pass
+    sp = stream.cuda_stream
+    key = (dev.type, dev.index, sp)
+    st = C.c_void_p(sp)
+    counters = _ws.get_counter_block(dev, _COUNTER_BYTES or _counter_bytes(lib), key)
+    fr.sh_jacobian = bool(fused and need_grad and _sh_jacobian)   # 48 bytes per Gaussian that spare the backward the 192 bytes of SH coefficients
+    chk = _deferred_stack[-1] if deferred else None
+    pinned, slot = _ws.next_pinned(dev, key, chk)
+    ready = _ws.get_event(dev, fresh=deferred, key=key)
+    wants_stages = _timer is not None and (_timer.only is None or _timer.only & _FORWARD_STAGES)
+    if deferred and _composite and not wants_stages:
+        # ---- the whole forward pass in one call, on one arena
+        H, W = view.H, view.W
+        flags = (_abi.GSPLAT_FRAME_BACKWARD if need_grad else 0) | (0 if _sh_jacobian else _abi.GSPLAT_FRAME_NO_SH_JACOBIAN)
+        frame_bytes, scratch_bytes = _ws.frame_sizes(lib, n, capacity, view, flags)
+        fr.arena = torch.empty(frame_bytes, dtype=torch.uint8, device=dev)
+        image = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+        scratch = _ws.get_scratch(dev, scratch_bytes, key)
+        fr.gaussians, fr.n_pairs = g, capacity
+        _abi.check(lib.gsplat_forward_deferred(g, c2w32.data_ptr(), view, fr.arena.data_ptr(), frame_bytes, capacity, counters.data_ptr(),
+                                               counters.numel(), scratch.data_ptr(), scratch.numel(), pinned.data_ptr(), ready.cuda_event,
+                                               image.data_ptr(), flags, st), "gsplat_forward_deferred")
+        forward_modes["deferred"] += 1
+        composite_calls["forward"] += 1
+        chk.add(pinned, ready, capacity, dev, ckey, (key, slot))
+        return None, (image, fr, None)
     pend = _Pending()
-    pend.frame, pend.gaussians, pend.device = fr, g, dev
-    with torch.cuda.device(dev):
-        pend.stream = torch.cuda.current_stream(dev)                  # looked up ONCE per half of the forward pass
-        pend.key = key = (dev.type, dev.index, pend.stream.cuda_stream)
-        pend.st = C.c_void_p(pend.stream.cuda_stream)
-        fr.proj_state = torch.empty(lib.gsplat_project_state_bytes(n, C.byref(view)), dtype=torch.uint8, device=dev)
-        counters = _ws.get_counter_block(dev, lib.gsplat_project_scratch_bytes(n), key)
-        deferred = bool(_deferred_stack) and _ws.pair_capacity(dev) > 0
-        pend.capacity = _ws.pair_capacity(dev) if deferred else None
-        pend.pinned = _ws.next_pinned(dev, key)
-        pend.ready = _ws.get_event(dev, fresh=deferred, key=key)
-        # the counters go straight into the pinned block (mapped into the device's address space: no copy operation);
-        # a frame that will not wait for them evaluates the SH colour inside the projection kernel and lets the first binning
-        # kernel total the counters (the projection's waves then retire without waiting for their stores)
-        flags = _abi.GSPLAT_PROJECT_COUNTS_MAPPED | ((_abi.GSPLAT_PROJECT_COLOUR_FUSED | _abi.GSPLAT_PROJECT_COUNTS_LATE) if deferred else 0)
-        # a backward pass will follow: the colour pass leaves 48 bytes per Gaussian that spare it the 192 bytes of SH coefficients
-        fr.sh_jacobian = bool(fused and need_grad and _sh_jacobian)
-        if fr.sh_jacobian:
-            flags |= _abi.GSPLAT_PROJECT_SAVE_SH_JACOBIAN
-        with _stage("project"):
-            _abi.check(lib.gsplat_project(C.byref(g), _p(c2w32), C.byref(view), _p(fr.proj_state), _p(counters),
-                                          counters.numel(), C.c_void_p(pend.pinned.data_ptr()), C.c_void_p(pend.ready.cuda_event),
-                                          flags, pend.st), "gsplat_project")
+    pend.frame, pend.gaussians, pend.device, pend.stream, pend.key, pend.st = fr, g, dev, stream, key, st
+    pend.capacity = capacity if deferred else None
+    pend.pinned, pend.ready, pend.ckey, pend.slot = pinned, ready, ckey, (key, slot)
+    fr.proj_state = torch.empty(lib.gsplat_project_state_bytes(n, C.byref(view)), dtype=torch.uint8, device=dev)
+    # the counters go straight into the pinned block (mapped into the device's address space: no copy operation);
+    # a frame that will not wait for them evaluates the SH colour inside the projection kernel and lets the first binning
+    # kernel total the counters (the projection's waves then retire without waiting for their stores)
+    flags = _abi.GSPLAT_PROJECT_COUNTS_MAPPED | ((_abi.GSPLAT_PROJECT_COLOUR_FUSED | _abi.GSPLAT_PROJECT_COUNTS_LATE) if deferred else 0)
+    if fr.sh_jacobian:
+        flags |= _abi.GSPLAT_PROJECT_SAVE_SH_JACOBIAN
+    with _stage("project"):
+        _abi.check(lib.gsplat_project(C.byref(g), _p(c2w32), C.byref(view), _p(fr.proj_state), _p(counters),
+                                      counters.numel(), C.c_void_p(pinned.data_ptr()), C.c_void_p(ready.cuda_event),
+                                      flags, st), "gsplat_project")
     return pend, None
+
+
+_COUNTER_BYTES = 0
+_FORWARD_STAGES = frozenset(("project", "bin", "raster_forward"))
+
+
+def _counter_bytes(lib):
+    global _COUNTER_BYTES
+    _COUNTER_BYTES = int(lib.gsplat_project_scratch_bytes(0))
+    return _COUNTER_BYTES
 
 
 def _forward_end(pend, need_grad):
@@ -339,45 +453,48 @@ def _forward_end(pend, need_grad):
     fr, dev = pend.frame, pend.device
     view, n = fr.view, fr.n
     H, W = view.H, view.W
-    with torch.cuda.device(dev):
-        st = pend.st                                 # (the same current stream as in the first half: the caller's contract)
-        # the one host wait of the forward pass: the pair count sizes the binning buffers, and the reference's empty /
-        # off-screen conventions need the survivor counts.  Only the counters are waited for: the first binning kernel and
-        # (fused inputs) the SH colour pass are queued behind them and run during this round trip.
-        image = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
-        if pend.capacity is not None:
-            # deferred: no wait.  Buffers of the capacity kept from earlier frames; the kernels read the real count on the
-            # device; the host looks at the counters in DeferredChecks.verify()
-            counts = None
-            fr.n_pairs = int(pend.capacity)
-            forward_modes["deferred"] += 1
-            _deferred_stack[-1].add(pend.pinned, pend.ready, fr.n_pairs, dev)
-        else:
-            pend.ready.synchronize()
-            forward_modes["waited"] += 1
-            counts = _abi.Counts.from_buffer_copy(pend.pinned.numpy().tobytes())
-            _ws.note_pairs(dev, counts.n_binned)
-            scene = lib.gsplat_classify_counts(C.byref(counts))
-            if scene == _abi.GSPLAT_SCENE_ALL_OFFSCREEN:
-                raise Exception(OFFSCREEN_MSG)
-            if scene == _abi.GSPLAT_SCENE_ALL_CULLED:
-                fr.empty = True
-                fr.proj_state = None
-                return image.zero_(), fr, counts
-            fr.n_pairs = int(counts.n_binned)        # pairs actually binned (16 x 8 lists); counts.n_pairs = the reference's P
-        fr.bin_state = torch.empty(lib.gsplat_bin_state_bytes(fr.n_pairs, C.byref(view)), dtype=torch.uint8, device=dev)
-        scratch = _ws.get_scratch(dev, lib.gsplat_bin_scratch_bytes(fr.n_pairs, C.byref(view)), pend.key)
-        with _stage("bin"):
-            _abi.check(lib.gsplat_bin(n, fr.n_pairs, C.byref(view), _p(fr.proj_state), _p(fr.bin_state), _p(scratch),
-                                      scratch.numel(), st), "gsplat_bin")
-        fr.accum = torch.empty((H, W, 3), dtype=torch.float32, device=dev) if need_grad else None
-        # the forward rasterizer clears the backward's accumulation buffer on the side (its waves are VALU-bound), unless
-        # there are so few lists that a wave's share would be long
-        lists = ((W + 15) // 16) * ((H + 7) // 8)
-        fr.grad2d = torch.empty((n, 16), dtype=torch.float32, device=dev) if need_grad and n <= 256 * lists else None
-        with _stage("raster_forward"):
-            _abi.check(lib.gsplat_rasterize_forward(n, fr.n_pairs, C.byref(view), _p(fr.proj_state), _p(fr.bin_state),
-                                                    _p(image), _p(fr.accum), _p(fr.grad2d), st), "gsplat_rasterize_forward")
+    st = pend.st                                 # (the same current stream as in the first half: the caller's contract)
+    # the one host wait of the forward pass: the pair count sizes the binning buffers, and the reference's empty /
+    # off-screen conventions need the survivor counts.  Only the counters are waited for: the first binning kernel and
+    # (fused inputs) the SH colour pass are queued behind them and run during this round trip.
+    image = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+    if pend.capacity is not None:
+        # deferred: no wait.  Buffers of the capacity kept from earlier frames; the kernels read the real count on the
+        # device; the host looks at the counters in DeferredChecks.verify()
+        counts = None
+        fr.n_pairs = int(pend.capacity)
+        forward_modes["deferred"] += 1
+        _deferred_stack[-1].add(pend.pinned, pend.ready, fr.n_pairs, dev, pend.ckey, pend.slot)
+    else:
+        pend.ready.synchronize()
+        forward_modes["waited"] += 1
+        counts = _abi.Counts.from_buffer_copy(pend.pinned.numpy().tobytes())
+        _ws.note_pairs(pend.ckey, counts.n_binned)
+        if _deferred_stack:                      # a frame that had to wait inside a deferred block (first of its size): verify() still
+            chk = _deferred_stack[-1]            # returns one entry per frame, in frame order (the earlier frames are done by now)
+            chk._drain(len(chk.pending))
+            chk.counts.append(counts)
+        scene = lib.gsplat_classify_counts(C.byref(counts))
+        if scene == _abi.GSPLAT_SCENE_ALL_OFFSCREEN:
+            raise Exception(OFFSCREEN_MSG)
+        if scene == _abi.GSPLAT_SCENE_ALL_CULLED:
+            fr.empty = True
+            fr.proj_state = None
+            return image.zero_(), fr, counts
+        fr.n_pairs = int(counts.n_binned)        # pairs actually binned (16 x 8 lists); counts.n_pairs = the reference's P
+    fr.bin_state = torch.empty(lib.gsplat_bin_state_bytes(fr.n_pairs, C.byref(view)), dtype=torch.uint8, device=dev)
+    scratch = _ws.get_scratch(dev, lib.gsplat_bin_scratch_bytes(fr.n_pairs, C.byref(view)), pend.key)
+    with _stage("bin"):
+        _abi.check(lib.gsplat_bin(n, fr.n_pairs, C.byref(view), _p(fr.proj_state), _p(fr.bin_state), _p(scratch),
+                                  scratch.numel(), st), "gsplat_bin")
+    fr.accum = torch.empty((H, W, 3), dtype=torch.float32, device=dev) if need_grad else None
+    # the forward rasterizer clears the backward's accumulation buffer on the side (its waves are VALU-bound), unless
+    # there are so few lists that a wave's share would be long
+    lists = ((W + 15) // 16) * ((H + 7) // 8)
+    fr.grad2d = torch.empty((n, 16), dtype=torch.float32, device=dev) if need_grad and n <= 256 * lists else None
+    with _stage("raster_forward"):
+        _abi.check(lib.gsplat_rasterize_forward(n, fr.n_pairs, C.byref(view), _p(fr.proj_state), _p(fr.bin_state),
+                                                _p(image), _p(fr.accum), _p(fr.grad2d), st), "gsplat_rasterize_forward")
     return image, fr, counts
 
 
@@ -389,13 +506,11 @@ def _forward_impl(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad):
 def _flat_like(ins):
     """One flat fp32 buffer holding a gradient for every input (each view 256-byte aligned inside it).  The data-parallel
     helper recognises the shared base and all-reduces the six gradients with ONE in-place collective, no flatten copy."""
-    offs, total = {}, 0
-    for k, v in ins.items():
-        offs[k] = total
-        total += (v.numel() + 63) // 64 * 64
+    sizes = [(v.numel() + 63) // 64 * 64 for v in ins.values()]
     any_in = next(iter(ins.values()))
-    flat = torch.empty(total, dtype=torch.float32, device=any_in.device)
-    return {k: flat[offs[k]:offs[k] + v.numel()].view(v.shape) for k, v in ins.items()}
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=any_in.device)
+    parts = flat.split(sizes)                                   # one call for all the pieces
+    return {k: (piece if piece.numel() == v.numel() else piece[:v.numel()]).view(v.shape) for (k, v), piece in zip(ins.items(), parts)}
 
 
 # Data-parallel exchange of the SH gradients in factored form (DESIGN.md §7, dp.FactoredExchange): while a sink is installed
@@ -427,22 +542,46 @@ def _backward_impl(fr, grad_image):
     dev = ins["pos"].device
     # the sink only takes over for the parameter tensors it was built for: a render of other tensors (an evaluation
     # model, a test) while a sink is installed keeps its ordinary SH gradients
-    factored = fr.fused and _sh_sink is not None and getattr(_sh_sink, "owns", lambda _ins: True)(ins)
+    factored = fr.fused and _sh_sink is not None and getattr(_sh_sink, "owns", lambda _ins, _ptrs=None: True)(ins, fr.src_ptrs)
     if fr.empty or fr.n == 0:
         if factored:
             _sh_sink.add(torch.zeros((fr.n, 3), dtype=torch.float32, device=dev), fr.c2w[:3, 3])
             return {k: (None if k in ("f_dc", "f_rest") else torch.zeros_like(v)) for k, v in ins.items()}
         return {k: torch.zeros_like(v) for k, v in ins.items()}
     gi = _f32(grad_image, (fr.view.H, fr.view.W, 3), "grad_image")
+    if torch.cuda.current_device() != dev.index:
+        torch.cuda.set_device(dev)
     stream = torch.cuda.current_stream(dev)
     st = C.c_void_p(stream.cuda_stream)
-    with torch.cuda.device(dev):
+    det = None
+    if _deterministic:
+        det = _ws.get_scratch(dev, lib.gsplat_rasterize_backward_scratch_bytes(fr.n, fr.n_pairs), (dev.type, dev.index, stream.cuda_stream))
+    out = _flat_like({k: v for k, v in ins.items() if not (factored and k in ("f_dc", "f_rest"))})
+    gg = _abi.GaussianGrads(_p(out["pos"]), _p(out["opacity_raw"]), _p(None if factored else out.get("color")), _p(out.get("sigma")),
+                            _p(out.get("scale_raw")), _p(out.get("q_raw")), _p(out.get("f_dc")), _p(out.get("f_rest")))
+    jac = _abi.GSPLAT_BACKWARD_SH_JACOBIAN if fr.sh_jacobian else 0
+    if fr.arena is not None:
+        # ---- the frame was queued by gsplat_forward_deferred: one call for the whole backward pass (two with a sink in between)
+        dirty = _abi.GSPLAT_BACKWARD_GRAD2D_DIRTY if fr.dirty else 0
+        fr.dirty = True                        # a second backward through the same graph must not reuse a dirty buffer
+        args = (fr.gaussians, fr.c2w.data_ptr(), fr.view, fr.arena.data_ptr(), fr.arena.numel(), fr.n_pairs, gi.data_ptr(), gg)
+        dargs = (det.data_ptr() if det is not None else None, det.numel() if det is not None else 0)
+        wants_stages = _timer is not None and (_timer.only is None or _timer.only & _BACKWARD_STAGES)
+        if factored or wants_stages:
+            glogit = torch.empty((fr.n, 3), dtype=torch.float32, device=dev) if factored else None
+            with _stage("raster_backward"):
+                _abi.check(lib.gsplat_backward(*args, _p(glogit), *dargs, jac | dirty | _abi.GSPLAT_BACKWARD_PHASE_RASTER, st), "gsplat_backward")
+            if factored:       # logit gradients first: the sink may start exchanging them while the projection backward runs
+                _sh_sink.add(glogit, fr.c2w[:3, 3])
+            with _stage("project_backward"):
+                _abi.check(lib.gsplat_backward(*args, None, None, 0, jac | _abi.GSPLAT_BACKWARD_PHASE_PROJECT, st), "gsplat_backward")
+        else:
+            _abi.check(lib.gsplat_backward(*args, None, *dargs, jac | dirty, st), "gsplat_backward")
+        composite_calls["backward"] += 1
+    else:
         zeroed = fr.grad2d is not None
         grad2d = fr.grad2d if zeroed else torch.empty((fr.n, 16), dtype=torch.float32, device=dev)
         fr.grad2d = None                       # a second backward through the same graph must not reuse a dirty buffer
-        det = None
-        if _deterministic:
-            det = _ws.get_scratch(dev, lib.gsplat_rasterize_backward_scratch_bytes(fr.n, fr.n_pairs), (dev.type, dev.index, stream.cuda_stream))
         with _stage("raster_backward"):
             _abi.check(lib.gsplat_rasterize_backward(fr.n, fr.n_pairs, C.byref(fr.view), _p(fr.proj_state), _p(fr.bin_state),
                                                      _p(fr.accum), _p(gi), _p(grad2d), int(zeroed), _p(det),
@@ -452,17 +591,16 @@ def _backward_impl(fr, grad_image):
             glogit = torch.empty((fr.n, 3), dtype=torch.float32, device=dev)
             _abi.check(lib.gsplat_logit_grad(fr.n, C.byref(fr.view), _p(fr.proj_state), _p(grad2d), _p(glogit), st), "gsplat_logit_grad")
             _sh_sink.add(glogit, fr.c2w[:3, 3])
-        out = _flat_like({k: v for k, v in ins.items() if not (factored and k in ("f_dc", "f_rest"))})
         g = _make_gaussians(fr.n, **ins)
-        gg = _abi.GaussianGrads(_p(out["pos"]), _p(out["opacity_raw"]), _p(None if factored else out.get("color")), _p(out.get("sigma")),
-                                _p(out.get("scale_raw")), _p(out.get("q_raw")), _p(out.get("f_dc")), _p(out.get("f_rest")))
         with _stage("project_backward"):
             _abi.check(lib.gsplat_project_backward(C.byref(g), _p(fr.c2w), C.byref(fr.view), _p(fr.proj_state), _p(grad2d),
-                                                   C.byref(gg), _abi.GSPLAT_BACKWARD_SH_JACOBIAN if fr.sh_jacobian else 0,
-                                                   st), "gsplat_project_backward")
+                                                   C.byref(gg), jac, st), "gsplat_project_backward")
     if factored:
         out["f_dc"] = out["f_rest"] = None
     return out
+
+
+_BACKWARD_STAGES = frozenset(("raster_backward", "project_backward"))
 
 
 def sh_accumulate(pos, eyes, grad_logit, scale=1.0):
@@ -564,7 +702,7 @@ def render_frames(pos, f_dc, f_rest, opacity_raw, scale_raw, q_raw, c2ws, H, W, 
     dev = pos.device
     cams = [torch.as_tensor(c, dtype=torch.float32, device=dev) if not isinstance(c, torch.Tensor) else c for c in c2ws]
     args = (view, dev, cams, pos, f_dc, f_rest, opacity_raw, scale_raw, q_raw)
-    if on_frame is not None or _ws.pair_capacity(dev) == 0 or _deferred_stack:
+    if on_frame is not None or _ws.pair_capacity(capacity_key(dev, view, pos.shape[0])) == 0 or _deferred_stack:
         return _render_frames(*args, on_frame)
     return run_deferred(lambda: _render_frames(*args, None))
 

@@ -104,28 +104,53 @@ class Trainer:
             exchange = dp.FactoredExchange(m.get_params(), world_views=1, group=self.group, equal_views=even) if world > 1 else None
             # no host synchronisation per view: the renders size their buffers from earlier frames, the per-frame checks
             # (off-screen exception, buffer capacity) are made ONCE, after the last backward is queued
-            with ops.deferred_checks() as checks, (exchange if exchange is not None else contextlib.nullcontext()):
-                for v in views:                                                        # (the gradient sink is always removed again)
-                    image_gt = torch.as_tensor(v['image']).to(dev)
-                    c2w = torch.as_tensor(v['c2w'], dtype=torch.float32).to(dev)
-                    rendered = ops.render_gaussians(m.pos, m.f_dc, m.f_rest, m.opacity_raw, m.scale_raw, m.q_raw, c2w,
-                                                    int(v['H']), int(v['W']), float(v['fx']), float(v['fy']), float(v['cx']), float(v['cy']))
-                    loss, vals = losses.compute_loss_device(rendered, image_gt, c.lambda_l1, c.lambda_ssim)
-                    (loss / n_global).backward()
-                    acc += vals / n_global
-            redo = 0
+            pass_error = None
+            try:
+                with ops.deferred_checks() as checks, (exchange if exchange is not None else contextlib.nullcontext()):
+                    for v in views:                                                    # (the gradient sink is always removed again)
+                        image_gt = torch.as_tensor(v['image']).to(dev)
+                        c2w = torch.as_tensor(v['c2w'], dtype=torch.float32).to(dev)
+                        rendered = ops.render_gaussians(m.pos, m.f_dc, m.f_rest, m.opacity_raw, m.scale_raw, m.q_raw, c2w,
+                                                        int(v['H']), int(v['W']), float(v['fx']), float(v['fy']), float(v['cx']), float(v['cy']))
+                        loss, vals = losses.compute_loss_device(rendered, image_gt, c.lambda_l1, c.lambda_ssim)
+                        (loss / n_global).backward()
+                        acc += vals / n_global
+            except Exception as e:                # single process: nothing to agree on, the exception leaves as it is
+                if world == 1:
+                    raise
+                pass_error = e
+            # ---- what happened on this rank, as ONE code; then ONE agreement over the ranks.  Nothing may leave this function
+            # between the first collective of the pass and the agreement: a rank that raised here while its peers sat in the
+            # exchange would leave them waiting for ever.
+            status, err = dp.STATUS_OK, None
             try:
                 checks.verify()
+                if exchange is not None and exchange.n_added != len(views):
+                    raise RuntimeError(f"{exchange.n_added} of this rank's {len(views)} views went through the factored exchange: a render "
+                                       "of this model took the ordinary backward (are f_dc / f_rest the model's own tensors?)")
             except ops.PairCapacityExceeded:
-                redo = 1                          # a view outgrew the buffers: this pass's gradients are invalid (capacity now raised)
-            if world > 1:                         # every rank repeats the pass or none does (the collectives must match)
-                redo = dp.any_rank(redo, self.group, device=dev)
+                status = dp.STATUS_REDO           # a view outgrew the buffers: this pass's gradients are invalid (capacity now raised)
+            except Exception as e:                # the reference's off-screen Exception (render.py:235-236), or anything else
+                status, err = (dp.STATUS_OFFSCREEN if str(e) == ops.OFFSCREEN_MSG else dp.STATUS_ERROR), e
+            if pass_error is not None:            # an exception inside the render loop itself (a frame that waited for its counters, a device error)
+                err = pass_error
+                status = dp.STATUS_OFFSCREEN if str(err) == ops.OFFSCREEN_MSG else dp.STATUS_ERROR
+            if world > 1:                         # every rank repeats the pass, or none does; every rank raises, or none does
+                if exchange is not None:
+                    exchange.pad_views(len(views))          # (a pass that stopped early: keep the sequence of collectives aligned)
+                status = dp.agree_status(status, self.group, device=dev)
             if exchange is not None:
-                if redo:
+                if status != dp.STATUS_OK:
                     exchange.abandon()
                 else:
                     exchange.finish()             # the loss was already divided by the global batch: world_views = 1
-            if not redo:
+            if status >= dp.STATUS_OFFSCREEN:
+                if err is not None:
+                    raise err
+                if status == dp.STATUS_OFFSCREEN:
+                    raise Exception(ops.OFFSCREEN_MSG + " (on another rank of the data-parallel group)")
+                raise RuntimeError("another rank of the data-parallel group failed in this training step")
+            if status == dp.STATUS_OK:
                 break
         else:
             raise RuntimeError("the pair buffers overflowed four times in a row")

@@ -218,6 +218,21 @@ def launch_check(args, rank, world):
     return 0
 
 
+def host_queue_ms(render_pass, ops, fence, steps=100):
+    """Milliseconds of HOST time to queue one step (Python + autograd + the library calls), measured with the GPU idle at the start and
+    never waited for inside the loop (fewer steps than a DeferredChecks block holds before it looks at its oldest frames).  When this
+    exceeds the GPU's time per step, the host is the bound."""
+    fence()
+    with ops.deferred_checks() as chk:
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            render_pass()
+        t1 = time.perf_counter()
+        fence()
+    chk.verify()
+    return (t1 - t0) / steps * 1e3
+
+
 def timed(fn, steps, fence):
     fence()
     t0 = time.perf_counter()
@@ -243,6 +258,10 @@ def main():
                     help="N > 1: SH gradients as logit gradients + local rebuild (DESIGN.md §7), or one all-reduce of all six tensors")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--launch-check", action="store_true", help="only check the rank launch + process group (no GPU needed)")
+    ap.add_argument("--deterministic", action="store_true", help="bitwise reproducible gradients (ops.set_deterministic): rows per "
+                    "(list, Gaussian) pair stored and added in a fixed order instead of float atomics")
+    ap.add_argument("--separate-calls", action="store_true", help="ablation: a deferred frame goes through the separate library calls "
+                    "(gsplat_project, gsplat_bin, ...) instead of the two composite entries")
     ap.add_argument("--wait-counts", action="store_true", help="every forward pass waits for its pair count (exact buffers) instead of "
                     "sizing them from earlier frames (ops.deferred_checks)")
     args = ap.parse_args()
@@ -286,6 +305,10 @@ def main():
     ops = importlib.import_module(PKG + ".ops")
     dp = importlib.import_module(PKG + ".dp")
 
+    if args.deterministic:
+        ops.set_deterministic(True)
+    if args.separate_calls:
+        ops._composite = False
     params_cpu, cam = synthetic_scene(args.config)
     N = params_cpu["pos"].shape[0]
     H, W = cam["H"], cam["W"]
@@ -389,6 +412,10 @@ def main():
         wins = [max_over_ranks(timed(step, per, fence)) for _ in range(10)]
         extras["sustained"] = {"seconds": sum(wins) * per / 1e3, "steps": 10 * per, "ms_per_step": sum(wins) / 10, "min_ms": min(wins),
                                "max_ms": max(wins), "windows": 10}
+    if not args.wait_counts:
+        extras["host_queue_ms"] = min(host_queue_ms(render_pass, ops, fence) for _ in range(3))
+        extras["host_calls_per_step"] = {"forward": "gsplat_forward_deferred (1 call, 1 arena)", "backward": "gsplat_backward (1 call)"} \
+            if ops._composite else {"forward": "gsplat_project + gsplat_bin + gsplat_rasterize_forward", "backward": "gsplat_rasterize_backward + gsplat_project_backward"}
     if not args.no_extras and not args.wait_counts and world == 1:
         # the same step through the call that WAITS for every frame's pair count in the middle of the forward pass (exact buffers,
         # exceptions raised by the call itself: what a caller that only switched the import gets)

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GSPLAT_ABI_VERSION 4
+#define GSPLAT_ABI_VERSION 5
 
 /* call status */
 #define GSPLAT_OK 0
@@ -197,6 +197,40 @@ int gsplat_rasterize_backward(int64_t n, int64_t pair_capacity, const gsplat_vie
 int gsplat_project_backward(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v,
                             const void* project_state, const float* grad2d, const gsplat_gaussian_grads* out,
                             int32_t flags, void* stream);
+
+/* ---- composite entries: one call per direction ----------------------------------------------------------------------
+ * For a host that does not wait for the counters in the middle of the forward pass (a training loop, a frame sequence:
+ * the pair buffers are sized from a capacity kept from earlier frames, see gsplat_bin) the forward pass is three library
+ * calls and five caller-owned buffers, the backward pass two or three calls; on a Python host every call and every
+ * allocation is several microseconds, and the whole step is ~0.5 ms of GPU time.  These two entries queue exactly the same
+ * kernels from ONE call each, on ONE caller-owned arena:
+ *
+ *   frame arena   gsplat_frame_bytes(n, pair_capacity, v, flags) bytes, 256-byte aligned: project_state | bin_state, and with
+ *                 GSPLAT_FRAME_BACKWARD also accum [H,W,3] | grad2d [n,16]; kept until the backward pass, private to the library.
+ *   gsplat_forward_deferred = gsplat_project(COLOUR_FUSED | COUNTS_LATE | COUNTS_MAPPED if counts_host | SAVE_SH_JACOBIAN if
+ *                 GSPLAT_FRAME_BACKWARD and fused inputs) + gsplat_bin + gsplat_rasterize_forward.  `counters` is
+ *                 gsplat_project's persistent counter block, `bin_scratch` gsplat_bin's scratch (gsplat_bin_scratch_bytes);
+ *                 counts_host (nullable) must be device-mapped pinned memory; counts_event (nullable) is recorded behind the
+ *                 counters.  The caller reads counts_host when it likes (n_binned > pair_capacity: the frame is garbage, render
+ *                 it again with larger buffers; survivors but nothing visible: the reference's off-screen exception).
+ *   gsplat_backward = gsplat_rasterize_backward [+ gsplat_logit_grad if grad_logit] + gsplat_project_backward on the same
+ *                 arena.  flags: GSPLAT_BACKWARD_SH_JACOBIAN as for gsplat_project_backward (set it iff the frame was made
+ *                 with GSPLAT_FRAME_BACKWARD from fused inputs without GSPLAT_FRAME_NO_SH_JACOBIAN);
+ *                 GSPLAT_BACKWARD_PHASE_RASTER / _PROJECT: only that half (a data-parallel host starts exchanging grad_logit
+ *                 between the two); GSPLAT_BACKWARD_GRAD2D_DIRTY: a second backward pass through the same frame.           */
+#define GSPLAT_FRAME_BACKWARD 1
+#define GSPLAT_FRAME_NO_SH_JACOBIAN 2
+#define GSPLAT_BACKWARD_PHASE_RASTER 2
+#define GSPLAT_BACKWARD_PHASE_PROJECT 4
+#define GSPLAT_BACKWARD_GRAD2D_DIRTY 8
+int64_t gsplat_frame_bytes(int64_t n, int64_t pair_capacity, const gsplat_view* v, int32_t flags);
+int gsplat_forward_deferred(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, void* frame,
+                            int64_t frame_bytes, int64_t pair_capacity, void* counters, int64_t counters_bytes,
+                            void* bin_scratch, int64_t bin_scratch_bytes, gsplat_counts* counts_host, void* counts_event,
+                            float* image, int32_t flags, void* stream);
+int gsplat_backward(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, void* frame, int64_t frame_bytes,
+                    int64_t pair_capacity, const float* grad_image, const gsplat_gaussian_grads* out, float* grad_logit,
+                    void* det_scratch, int64_t det_scratch_bytes, int32_t flags, void* stream);
 
 /* Data-parallel exchange helper: per view the SH-coefficient gradient is the outer product of the 3
  * colour-logit gradients with the 16 SH basis values of the view direction, so ranks exchange 12 B per Gaussian and view

@@ -47,6 +47,18 @@ def test_library_exports_every_declared_symbol():
     assert abi.lib().gsplat_abi_version() == abi.ABI_VERSION
 
 
+def test_library_exports_nothing_but_the_declared_entry_points():
+    """Every defined dynamic FUNCTION symbol of the product library is an entry point of include/gsplat_mi355x.h (a helper with C
+    linkage inside the extern "C" block would be exported silently: round 2's carve_det)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", abi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    funcs = [ln.split()[-1] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "TtWw"]
+    declared = set(_header_functions())
+    stray = [f for f in funcs if f not in declared and not f.startswith(("_init", "_fini", "__hip", "_ZN", "_ZT", "_ZS"))]
+    assert not stray, f"non-ABI symbols exported by the product library: {stray}"
+    assert not [f for f in funcs if f.startswith("gsplat_") and f not in declared], "exported gsplat_* symbol missing from the header"
+
+
 def test_struct_layouts_match_header():
     # sizes the C side static_asserts / uses: gsplat_view 14 x 4 B, gsplat_counts 32 B, 9 and 8 pointer-sized fields
     assert C.sizeof(abi.View) == 56

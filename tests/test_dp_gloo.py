@@ -209,3 +209,127 @@ def test_three_ranks_with_2_1_3_views_agree_on_the_exchange(given):
 def test_agree_on_views_rejects_inconsistent_hints():
     dp = importlib.import_module(PKG + ".dp")
     assert dp.agree_on_views(3) == (True, 3)                       # single process: nothing to agree on
+
+
+# ---- Trainer.step: one agreement per pass, whatever happens on a rank (host logic; the renderer is a toy: the HIP op needs a GPU) ----
+def _toy_trainer_worker(rank, world, port, q, mode):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ops = importlib.import_module(PKG + ".ops")
+    training = importlib.import_module(PKG + ".training")
+    losses = importlib.import_module(PKG + ".losses")
+    n = 33
+
+    class Model:
+        def __init__(self):
+            g = torch.Generator().manual_seed(11)
+            for k, s in (("pos", (n, 3)), ("f_dc", (n, 3)), ("f_rest", (n, 45)), ("opacity_raw", (n,)), ("scale_raw", (n, 3)), ("q_raw", (n, 4))):
+                setattr(self, k, torch.randn(*s, generator=g).requires_grad_(True))
+
+        def get_params(self):
+            return {k: getattr(self, k) for k in ("pos", "opacity_raw", "f_dc", "f_rest", "scale_raw", "q_raw")}
+
+        def get_num_gaussians(self):
+            return n
+
+    class Toy(torch.autograd.Function):          # hands its logit gradients to the installed sink, like the render backward
+        @staticmethod
+        def forward(ctx, pos, f_dc, f_rest, opa, scale, quat, c2w, weight):
+            ctx.c2w, ctx.weight = c2w, weight
+            ctx.src = (f_dc.data_ptr(), f_rest.data_ptr())
+            return (pos.sum() + opa.sum() + scale.sum() + quat.sum()) * torch.ones(2, 2, 3) * weight
+
+        @staticmethod
+        def backward(ctx, g):
+            s = float(g.sum()) * ctx.weight
+            sink = ops._sh_sink
+            factored = sink is not None and sink.owns({}, ctx.src)
+            if factored:
+                sink.add(torch.full((n, 3), s), ctx.c2w[:3, 3])
+            sh = (None, None) if factored else (torch.full((n, 3), s), torch.full((n, 45), s))
+            return torch.full((n, 3), s), sh[0], sh[1], torch.full((n,), s), torch.full((n, 3), s), torch.full((n, 4), s), None, None
+
+    calls = {"render": 0, "verify": 0}
+
+    def fake_render(pos, f_dc, f_rest, opa, scale, quat, c2w, *cam):
+        calls["render"] += 1
+        if mode == "render_raises" and rank == 1 and calls["render"] == 2:       # second of two views: one gather already issued
+            raise Exception(ops.OFFSCREEN_MSG)                                   # (a frame that waited for its counters)
+        return Toy.apply(pos, f_dc, f_rest, opa, scale, quat, c2w, 1.0 + rank)
+
+    real_verify = ops.DeferredChecks.verify
+
+    def fake_verify(self):
+        calls["verify"] += 1
+        if rank == 1 and mode == "verify_offscreen":
+            raise Exception(ops.OFFSCREEN_MSG)
+        if rank == 1 and mode == "other_error":
+            raise ValueError("a rank-local failure")
+        if rank == 0 and mode == "redo_once" and calls["verify"] == 1:
+            raise ops.PairCapacityExceeded("toy overflow")
+        return real_verify(self)
+
+    class Opt:
+        param_groups = [{"lr": 0.0}]
+
+        def zero_grad(self):
+            for p in model.get_params().values():
+                p.grad = None
+
+        def clip_grad_norm_(self, *a, **k):
+            pass
+
+        def step(self):
+            pass
+
+    ops.render_gaussians = fake_render
+    ops.DeferredChecks.verify = fake_verify
+    ops.sh_accumulate = lambda pos, eyes, logits, scale: (scale * logits.sum(0), scale * logits.sum(0).repeat(1, 15))
+    losses.compute_loss_device = lambda rendered, gt, a, b: (rendered.sum(), torch.zeros(3))
+    training.Trainer._new_optimizer = lambda self, lr: Opt()
+    model = Model()
+    tr = training.Trainer(model, training.TrainConfig(densify_until_iter=0, opacity_reset_interval=10 ** 9))
+    views = [dict(image=torch.zeros(2, 2, 3), c2w=torch.eye(4), H=2, W=2, fx=1., fy=1., cx=1., cy=1.) for _ in range(2)]
+    try:
+        tr.step(1, views)
+        q.put((rank, "ok", "", calls["render"], {k: p.grad.numpy().copy() for k, p in model.get_params().items()}))
+    except Exception as e:
+        q.put((rank, type(e).__name__, str(e), calls["render"], None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["verify_offscreen", "render_raises", "other_error", "redo_once", "fine"])
+def test_trainer_step_agrees_on_the_outcome_of_a_pass(mode):
+    """One rank's view has survivors but nothing on screen (found in verify(), or by a frame that waited for its counters after one
+    of its views' collectives was already issued), or it fails otherwise: EVERY rank raises within the timeout -- nobody is left
+    waiting in a collective.  One rank's pair buffers overflowed: both repeat the pass, and the gradients are those of a clean pass."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_toy_trainer_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r = q.get(timeout=120)
+        got[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ops = importlib.import_module(PKG + ".ops")
+    if mode in ("verify_offscreen", "render_raises"):
+        assert got[1][0] == "Exception" and got[1][1] == ops.OFFSCREEN_MSG                  # the reference's exception, where it happened
+        assert got[0][0] == "Exception" and got[0][1].startswith(ops.OFFSCREEN_MSG)         # ... and on the peer
+    elif mode == "other_error":
+        assert got[1][:2] == ("ValueError", "a rank-local failure")
+        assert got[0][0] == "RuntimeError" and "another rank" in got[0][1]
+    else:
+        assert got[0][0] == got[1][0] == "ok"
+        assert got[0][2] == got[1][2] == (4 if mode == "redo_once" else 2)                  # both ranks rendered their views twice, or once
+        for k in got[0][3]:
+            assert (got[0][3][k] == got[1][3][k]).all(), k                                  # replicas identical
+        # a view of rank r contributes 12 pixel values x (1 + r) / 4 views = 3 (1 + r) to every gradient element; two views per rank:
+        # 2 * 3 + 2 * 6 = 18 -- once, also when the pass was repeated (nothing of the abandoned pass may be left in the sums)
+        assert abs(got[0][3]["pos"] - 18.0).max() < 1e-5
+        assert abs(got[0][3]["f_dc"] - 18.0).max() < 1e-5

@@ -458,6 +458,12 @@ def _ops():
     return importlib.import_module("3d-gaussian-splatting-for-novel-view-synthesis_amd.ops")
 
 
+def _cap_key(ops, d):
+    """Where ops keeps the pair capacity of golden case d's frames: per (device, image size, Gaussian-count bucket)."""
+    import types
+    return ops.capacity_key(torch.device("cuda:0"), types.SimpleNamespace(H=d["H"], W=d["W"]), len(d["pos"]))
+
+
 def test_deferred_checks_render_the_same_frame_without_waiting(gs):
     """ops.deferred_checks(): buffers from the capacity kept from earlier frames, counters read once in verify(), SH colour
     inside the projection kernel -- the image is bit-identical to the waiting path, the gradients agree to summation order."""
@@ -481,7 +487,7 @@ def test_deferred_checks_report_overflow_offscreen_and_empty_scenes(gs):
     ops = _ops()
     d = util.load("g1_generic")
     _fused(gs, d, grad=False)
-    key = ("cuda", 0)
+    key = _cap_key(ops, d)
     real = ops._ws.capacity[key]
     try:
         ops._ws.capacity[key] = 64                              # far fewer pairs than the frame has (1616)
@@ -594,7 +600,7 @@ def test_deterministic_backward_with_too_small_buffers_is_memory_safe(gs):
     ops = _ops()
     d = util.load("g1_generic")
     _fused(gs, d, grad=False)
-    key = ("cuda", 0)
+    key = _cap_key(ops, d)
     real = ops._ws.capacity[key]
     old = gs.set_deterministic(True)
     try:
@@ -636,3 +642,102 @@ def test_the_ctypes_stub_of_integration_md_renders_the_golden(gs):
     util.check_image(img.cpu().numpy(), d["image"])
     again = gs.render(t["pos"], col, t["opacity_raw"], sig, torch.tensor(d["c2w"], device=DEV), *util.cam_args(d))
     assert torch.equal(img, again)
+
+
+def test_composite_entries_queue_the_same_frame_as_the_separate_calls(gs):
+    """gsplat_forward_deferred / gsplat_backward (ONE library call per direction on ONE arena) against the separate calls a deferred
+    frame used to make: the same kernels on the same inputs -- bit-identical image, and in deterministic mode bit-identical
+    gradients; a second backward pass through the same frame (retain_graph) is right too."""
+    ops = _ops()
+    d = util.load("g1_generic")
+    _fused(gs, d, grad=False)                                    # leaves a pair capacity
+    old = gs.set_deterministic(True)
+    try:
+        res = {}
+        for composite in (True, False):
+            ops._composite = composite
+            before = dict(ops.composite_calls)
+            with ops.deferred_checks() as chk:
+                img, p = _fused(gs, d)
+                img_ng, _ = _fused(gs, d, grad=False)
+            chk.verify()
+            took = (ops.composite_calls["forward"] - before["forward"], ops.composite_calls["backward"] - before["backward"])
+            assert took == ((2, 1) if composite else (0, 0))
+            res[composite] = (img.detach().clone(), img_ng.clone(), {k: p[k].grad.clone() for k in util.PARAMS})
+        assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][0], res[True][1])
+        for k in util.PARAMS:
+            assert torch.equal(res[True][2][k], res[False][2][k]), k
+            util.check_grad(res[True][2][k].cpu().numpy(), d["grad_" + k], k, cal=d["grad32_" + k])
+        # two backward passes through one composite frame: the second must not add to the first one's sums
+        ops._composite = True
+        with ops.deferred_checks() as chk:
+            p = util.tensors(d, F32, "cuda", grad=True)
+            img = gs.render_gaussians(p["pos"], p["f_dc"], p["f_rest"], p["opacity_raw"], p["scale_raw"], p["q_raw"],
+                                      torch.tensor(d["c2w"], dtype=F32, device="cuda"), *util.cam_args(d), **d["kwargs"])
+            w = torch.tensor(d["wrand"], dtype=F32, device="cuda")
+            (img * w).sum().backward(retain_graph=True)
+            first = {k: p[k].grad.clone() for k in util.PARAMS}
+            for k in util.PARAMS:
+                p[k].grad = None
+            (img * w).sum().backward()
+        chk.verify()
+        for k in util.PARAMS:
+            assert torch.equal(first[k], p[k].grad), k
+    finally:
+        ops._composite = True
+        gs.set_deterministic(old)
+
+
+def test_a_deferred_block_left_without_verify_never_hands_out_an_unread_counter_block(gs):
+    """DeferredChecks robustness: (1) a block left by an exception reads its frames' counters then and there and raises nothing of
+    its own; (2) a block that is simply never verified keeps its pinned counter blocks until the ring comes round, and then they are
+    read -- by their owner -- BEFORE another frame gets them: the late verify() still reports that block's own frames."""
+    ops = _ops()
+    d = util.load("g1_generic")
+    _fused(gs, d, grad=False)
+    with pytest.raises(ZeroDivisionError):
+        with ops.deferred_checks() as chk:
+            _fused(gs, d, grad=False)
+            1 / 0
+    assert not chk.pending and len(chk.counts) == 1 and chk.counts[0].n_visible == len(d["im_ids"])
+    off = util.load("g10_offscreen")
+    _ = _cap_key(ops, off)
+    with ops.deferred_checks() as abandoned:                     # never verified (yet)
+        _fused(gs, d, grad=False)
+        _fused(gs, off, grad=False) if ops._ws.pair_capacity(_cap_key(ops, off)) else None
+    n_pending = len(abandoned.pending)
+    assert n_pending >= 1
+    for _ in range(3):                                           # more frames than the ring has slots: it comes round
+        with ops.deferred_checks() as chk:
+            for _ in range(ops.PINNED_SLOTS // 2 - 8):
+                _fused(gs, d, grad=False)
+        assert all(c.n_visible == len(d["im_ids"]) for c in chk.verify())
+    assert not abandoned.pending and len(abandoned.counts) == n_pending          # read when the ring reached them, not overwritten
+    assert abandoned.counts[0].n_visible == len(d["im_ids"]) and abandoned.counts[0].n_pairs == len(d["im_pair_gauss"])
+
+
+def test_pair_capacity_is_kept_per_image_size_and_gaussian_count(gs):
+    """A large scene must not make every later frame of a small one pay for its pair capacity (buffers, grids, the deterministic
+    mode's clear): capacities live per (device, image size, power-of-two bucket of N); reset_pair_capacity() forgets them."""
+    ops = _ops()
+    small, big = util.load("g1_generic"), util.load("g3_occlusion")
+    ks, kb = _cap_key(ops, small), _cap_key(ops, big)
+    _fused(gs, small, grad=False)
+    cap_small = ops._ws.pair_capacity(ks)
+    _fused(gs, big, grad=False)
+    assert ks != kb and cap_small > 0 and ops._ws.pair_capacity(kb) > 0
+    assert ops._ws.pair_capacity(ks) == cap_small                 # the other scene's pairs left it alone
+    with ops.deferred_checks() as chk:
+        img, _ = _fused(gs, small, grad=False)
+    chk.verify()
+    util.check_image(img.cpu().numpy(), small["image"], cal=small["image_f32"])
+    saved = dict(ops._ws.capacity)
+    try:
+        ops.reset_pair_capacity()
+        before = dict(ops.forward_modes)
+        with ops.deferred_checks() as chk:                       # nothing known any more: this frame waits like an ordinary one
+            _fused(gs, small, grad=False)
+        chk.verify()
+        assert ops.forward_modes["waited"] == before["waited"] + 1
+    finally:
+        ops._ws.capacity.update(saved)

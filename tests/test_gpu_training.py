@@ -288,13 +288,15 @@ def test_trainer_repeats_a_pass_that_outgrew_the_pair_buffers():
         tr = training.Trainer(model, training.TrainConfig(densify_until_iter=0, opacity_reset_interval=10 ** 9))
         tr.step(1, views)
         if shrink:
-            ops._ws.capacity[("cuda", 0)] = 100               # far below the ~1600 pairs of a view
+            import types
+            key = ops.capacity_key(torch.device("cuda:0"), types.SimpleNamespace(H=views[0]["H"], W=views[0]["W"]), len(s["pos"]))
+            ops._ws.capacity[key] = 100                       # far below the ~1600 pairs of a view
         before = dict(ops.forward_modes)
         out = tr.step(2, views)
         torch.cuda.synchronize()
         if shrink:                                            # one garbage pass + one good pass, nothing waited for
             assert ops.forward_modes["deferred"] == before["deferred"] + 4 and ops.forward_modes["waited"] == before["waited"]
-            assert ops._ws.capacity[("cuda", 0)] > 1600
+            assert ops._ws.capacity[key] > 1600
         return float(out["loss"]), {k: getattr(model, k).detach().clone() for k in NAMES}
 
     loss_a, pa = run(False)
@@ -302,3 +304,70 @@ def test_trainer_repeats_a_pass_that_outgrew_the_pair_buffers():
     assert abs(loss_a - loss_b) <= 1e-6 * abs(loss_a)
     for k in NAMES:      # same update up to the summation order of the gradient atomics
         assert float((pa[k] - pb[k]).abs().max()) <= 1e-5 * max(1.0, float(pa[k].abs().max())), k
+
+
+def _dp_offscreen_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model_mod = importlib.import_module(PKG + ".model")
+    training = importlib.import_module(PKG + ".training")
+    s = scenes.case_g10()                                        # 48 Gaussians whose centres project into the guard band LEFT of a 32 x 32 image
+    model = model_mod.GaussianModel({k: torch.tensor(s[k]) for k in NAMES}, device="cuda:0")
+    tr = training.Trainer(model, training.TrainConfig(densify_until_iter=0, opacity_reset_interval=10 ** 9))
+    target = np.random.default_rng(9).uniform(0, 1, (s["H"], s["W"], 3)).astype(np.float32)
+    good = dict(image=target, c2w=s["c2w"], H=s["H"], W=s["W"], fx=s["fx"], fy=s["fy"], cx=s["cx"] + 40.0, cy=s["cy"])   # shifted: on screen
+    tr.step(1, [good], global_views=world)                      # a good iteration first: leaves the pair capacity (later frames do not wait)
+    bad = dict(good, cx=s["cx"]) if rank == 1 else good         # rank 1: survivors (guard band), nothing on screen
+    before = {k: getattr(model, k).detach().clone() for k in NAMES}
+    try:
+        tr.step(2, [bad], global_views=world)
+        q.put((rank, "ok", ""))
+    except Exception as e:
+        unchanged = all(torch.equal(before[k], getattr(model, k).detach()) for k in NAMES)
+        q.put((rank, type(e).__name__, str(e) + ("" if unchanged else " [parameters changed]")))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_an_offscreen_view_on_one_rank_raises_on_every_rank():
+    """Data parallel, real renderer: rank 1's view has survivors but nothing on screen.  The reference raises
+    Exception("All projected points are off-screen") for such a view; here EVERY rank raises it, in the same step, within the
+    timeout (nobody waits in a collective), and no rank has stepped its optimiser."""
+    import socket
+    import torch.multiprocessing as mp
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_offscreen_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((r, (name, msg)) for r, name, msg in (q.get(timeout=300) for _ in range(2)))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ops = importlib.import_module(PKG + ".ops")
+    assert got[1] == ("Exception", ops.OFFSCREEN_MSG), got
+    assert got[0][0] == "Exception" and got[0][1].startswith(ops.OFFSCREEN_MSG) and "changed" not in got[0][1], got
+
+
+def test_a_model_whose_sh_tensors_are_converted_by_the_render_is_not_silently_left_out_of_the_exchange():
+    """dp.FactoredExchange.owns() compares the caller's OWN f_dc / f_rest tensors (before the host's dtype / layout conversion):
+    a float64 model still goes through the factored exchange, and Trainer.step would raise if a view did not."""
+    gs = importlib.import_module(PKG)
+    dp = importlib.import_module(PKG + ".dp")
+    s, views = _scene()
+    v = views[0]
+    p = {k: torch.tensor(s[k], dtype=torch.float64, device="cuda:0").requires_grad_(True) for k in NAMES}
+    ex = dp.FactoredExchange(p, world_views=1)
+    with ex:
+        img = gs.render_gaussians(*[p[k] for k in ("pos", "f_dc", "f_rest", "opacity_raw", "scale_raw", "q_raw")],
+                                  torch.tensor(v["c2w"], device="cuda:0"), v["H"], v["W"], v["fx"], v["fy"], v["cx"], v["cy"])
+        (img * torch.tensor(v["image"], device="cuda:0")).sum().backward()
+    assert ex.n_added == 1 and p["f_dc"].grad is None            # the SH gradients went to the exchange, not into .grad
+    ex.finish()
+    assert p["f_dc"].grad is not None and float(p["f_rest"].grad.abs().max()) > 0

@@ -33,30 +33,32 @@ def step():
 
 step()                                   # the first frame on a device waits for its counters (sizes the buffers)
 torch.cuda.synchronize()
-for rep in range(3):
-    with ops.deferred_checks() as chk:
-        for _ in range(20):
-            step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(K):
-            step()
-        t1 = time.perf_counter()
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-    chk.verify()
-    print(f"host queues a step in {(t1 - t0) / K * 1e3:.3f} ms; the GPU finishes {(t2 - t1) * 1e3:.1f} ms after the host; "
-          f"{(t2 - t0) / K * 1e3:.3f} ms per step over all")
+
+
+def fence():
+    torch.cuda.synchronize()
+
+
+for composite in (True, False):
+    ops._composite = composite
+    for _ in range(20):
+        gs.run_deferred(step)
+    hq = [bench.host_queue_ms(step, ops, fence, steps=min(K, 100)) for _ in range(5)]
+    t = bench.timed(lambda: gs.run_deferred(step), 200, fence)
+    print(f"{'composite entries' if composite else 'separate calls   '}: host queues a step in {min(hq):.3f} ms (min of 5; max {max(hq):.3f}); "
+          f"{t:.3f} ms per step with the GPU")
+ops._composite = True
 
 if len(sys.argv) > 3 and sys.argv[3] == "profile":          # where the host's time goes (cProfile inflates it ~2x)
     import cProfile
     import pstats
     pr = cProfile.Profile()
+    torch.cuda.synchronize()
     with ops.deferred_checks() as chk:
         pr.enable()
-        for _ in range(K):
+        for _ in range(100):
             step()
         pr.disable()
         torch.cuda.synchronize()
     chk.verify()
-    pstats.Stats(pr).sort_stats("tottime").print_stats(28)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(32)
