@@ -72,6 +72,7 @@ GS_HD void build_camera(const float* c2w, Camera& c) {
 struct CovMid {
     float s[3];        // clamped scales
     float e[3];        // exp(scale_raw)
+    float r[3];        // scale_raw
     float q[4];        // normalised quaternion
     float qn;          // |q_raw|
     float R[9];
@@ -86,7 +87,7 @@ GS_HD void quat_to_rot(const float q[4], float R[9]) {
 }
 
 GS_HD void cov_from_params(const float scale_raw[3], const float q_raw[4], float S[6], CovMid& m) {
-    for (int k = 0; k < 3; ++k) { m.e[k] = expf(scale_raw[k]); m.s[k] = fmaxf(m.e[k], 1e-6f); }
+    for (int k = 0; k < 3; ++k) { m.r[k] = scale_raw[k]; m.e[k] = expf(scale_raw[k]); m.s[k] = fmaxf(m.e[k], 1e-6f); }
     m.qn = sqrtf(q_raw[0] * q_raw[0] + q_raw[1] * q_raw[1] + q_raw[2] * q_raw[2] + q_raw[3] * q_raw[3]);
     const float inv = 1.0f / (m.qn + 1e-9f);
     for (int k = 0; k < 4; ++k) m.q[k] = q_raw[k] * inv;
@@ -99,6 +100,12 @@ GS_HD void cov_from_params(const float scale_raw[3], const float q_raw[4], float
     S[3] = R[3] * R[3] * d0 + R[4] * R[4] * d1 + R[5] * R[5] * d2;
     S[4] = R[3] * R[6] * d0 + R[4] * R[7] * d1 + R[5] * R[8] * d2;
     S[5] = R[6] * R[6] * d0 + R[7] * R[7] * d1 + R[8] * R[8] * d2;
+}
+
+// s_i^2 - s_j^2 of the clamped scales
+GS_HD float cov_d_diff(const CovMid& m, int i, int j) {
+    if (m.e[i] >= 1e-6f && m.e[j] >= 1e-6f) return m.s[j] * m.s[j] * expm1f(2.f * (m.r[i] - m.r[j]));
+    return (m.s[i] - m.s[j]) * (m.s[i] + m.s[j]);
 }
 
 // B3 (covariance part).  G = dL/dS as a full symmetric 3x3 (row-major 9), i.e. dL = sum_ij G_ij dS_ij.
@@ -119,6 +126,10 @@ GS_HD void cov_from_params_backward(const float q_raw[4], const CovMid& m, const
         g_scale_raw[k] = (m.e[k] >= 1e-6f) ? ds * m.e[k] : 0.f;
     }
     const float x = m.q[0], y = m.q[1], z = m.q[2], w = m.q[3];
+    // dL/dq by the chain rule through quat_to_rot.  Its TANGENTIAL part (the one that survives the normalisation below) is a
+    // difference of large terms -- sums like dR[7] - dR[5] extract the antisymmetric part of dR R^T = 2 G Sigma, which vanishes
+    // as the scales approach each other: for a near-isotropic Gaussian the rounding of G R (1e-7 of |G| d) is then larger than
+    // the result (~ |G| (d_i - d_j)), and the rotation gradient of that Gaussian came out 20x less accurate than autograd's.
     float dq[4];
     dq[0] = 2.f * (y * (dR[1] + dR[3]) + z * (dR[2] + dR[6]) - 2.f * x * (dR[4] + dR[8]) + w * (dR[7] - dR[5]));
     dq[1] = 2.f * (x * (dR[1] + dR[3]) + z * (dR[5] + dR[7]) - 2.f * y * (dR[0] + dR[8]) + w * (dR[2] - dR[6]));
@@ -127,6 +138,30 @@ GS_HD void cov_from_params_backward(const float q_raw[4], const CovMid& m, const
     // q = q_raw / (n + eps)
     const float ne = m.qn + 1e-9f;
     const float dot = dq[0] * q_raw[0] + dq[1] * q_raw[1] + dq[2] * q_raw[2] + dq[3] * q_raw[3];
+    if (m.qn > 1e-4f) {
+        // The same gradient without the cancellation.  A rotation of the Gaussian's own axes by d phi changes
+        // Sigma = R D R^T by R [[d phi]x, D] R^T, so dL = tau . d phi with the torque (body frame, G' = R^T G R)
+        //     tau_x = 2 G'_12 (d_1 - d_2),  tau_y = 2 G'_02 (d_2 - d_0),  tau_z = 2 G'_01 (d_0 - d_1):
+        // proportional to the scale differences by construction (exactly zero for equal scales).  A unit quaternion moves by
+        // dq = 1/2 q (x) (d phi, 0), whose 4 x 3 matrix M(q) has orthonormal columns: the tangential gradient is 2 M(q) tau.
+        // q is a unit quaternion up to eps / |q_raw| = 1e-9 / n here (n > 1e-4: below fp32 resolution).  What the
+        // normalisation does to the RADIAL part of dL/dq -- it survives with the factor eps / (n + eps)^2 -- is kept from the
+        // chain-rule form, where it is a plain sum.
+        const float gp01 = R[0] * GR[1] + R[3] * GR[4] + R[6] * GR[7];
+        const float gp02 = R[0] * GR[2] + R[3] * GR[5] + R[6] * GR[8];
+        const float gp12 = R[1] * GR[2] + R[4] * GR[5] + R[7] * GR[8];
+        // d_i - d_j = d_j expm1(2 (r_i - r_j)) from the raw log-scales: the difference of two nearly equal r is exact, so the
+        // result keeps its 1e-7 where s_i - s_j (two rounded exponentials) would be down to 1e-7 / |r_i - r_j|
+        const float tx = 2.f * gp12 * cov_d_diff(m, 1, 2);
+        const float ty = 2.f * gp02 * cov_d_diff(m, 2, 0);
+        const float tz = 2.f * gp01 * cov_d_diff(m, 0, 1);
+        const float gt[4] = {2.f * (w * tx - z * ty + y * tz), 2.f * (z * tx + w * ty - x * tz), 2.f * (-y * tx + x * ty + w * tz),
+                             -2.f * (x * tx + y * ty + z * tz)};
+        const float radial = dot * 1e-9f / (m.qn * m.qn * ne * ne);          // (g . q_hat) eps / ne^2, times q_hat = q_raw / n
+        for (int k = 0; k < 4; ++k) g_q_raw[k] = gt[k] / ne + q_raw[k] * radial;
+        return;
+    }
+    // tiny |q_raw| (comparable with the reference's eps): R(q) is not a rotation there; the plain chain rule
     const float c = (m.qn > 0.f) ? dot / (m.qn * ne * ne) : 0.f;
     for (int k = 0; k < 4; ++k) g_q_raw[k] = dq[k] / ne - q_raw[k] * c;
 }

@@ -400,6 +400,10 @@ __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const f
             }
         }
         out.tiles[i] = r.tiles;
+#ifdef GSPLAT_DIAGNOSTICS
+        if (out.ref_rect) out.ref_rect[i] = r.ref_rect;
+        if (out.ref_tiles) out.ref_tiles[i] = r.vis == VIS_OK ? r.ref_tiles : 0u;
+#endif
     }
     const unsigned long long surv = __ballot(o.vis != VIS_CULLED);
     const unsigned long long seen = __ballot(o.vis == VIS_OK);
@@ -1091,6 +1095,13 @@ __global__ __launch_bounds__(256) void list_sort_small_kernel(const uint32_t* __
 typedef float v2f __attribute__((ext_vector_type(2)));
 // Exact ellipse / sub-tile test at staging time (subtile_mask_exact), measured on one box: the backward, whose iterations cost
 // 2.5x the forward's, gains (217 -> 207 us); the forward loses (85.6 -> 91.5 us) and keeps the box test.
+// GSPLAT_TWO_LEVEL=1: colour (forward) and suffix sums (backward) are formed per chunk and joined once per chunk -- fewer roundings
+// at full magnitude under hundreds of layers.  Costs 1.6 us in each raster kernel at config 3 and changed none of the measured
+// parity figures (the outliers it was written for turned out to be chi-square flips on the far end of needle-shaped Gaussians,
+// tools/moments_check.py): off.
+#ifndef GSPLAT_TWO_LEVEL
+#define GSPLAT_TWO_LEVEL 0
+#endif
 constexpr int CHUNK = 64;                            // list entries staged per round (one per lane)
 constexpr int QCAP = CHUNK + 8;                      // queue capacity: the inner loops read entries in pairs
 constexpr uint32_t NULL_OFF = CHUNK * 16;            // byte offset of the null record
@@ -1107,6 +1118,8 @@ __device__ __forceinline__ uint32_t xcc_id() {                // (every XCD has 
 #ifdef GSPLAT_DIAGNOSTICS
 WaveStats* g_stats_fwd = nullptr;
 WaveStats* g_stats_bwd = nullptr;
+u2* g_ref_rect = nullptr;            // tools/ref_pairs_diff.py: the reference's own tile rectangle (F10) and tile count per Gaussian
+uint32_t* g_ref_tiles = nullptr;
 #define STATS_FWD g_stats_fwd
 #define STATS_BWD g_stats_bwd
 #else
@@ -1347,6 +1360,15 @@ __global__ __launch_bounds__(64) void raster_forward_kernel(const uint2* __restr
         if (base < rg.y) cand = fetch_candidate(lane, base, rg.y, ids, rec, id_max);   // in flight during the loop below
         ++st_chunks;
         st_visited += (uint32_t)maxc;
+        // Two-level sum of the colour: the chunk's terms are added up from zero and join the running colour ONCE per chunk.  A
+        // pixel under several hundred layers otherwise rounds its running sum at full magnitude in every step; this way the
+        // roundings at full magnitude are one per chunk (the backward pass forms its suffix sums the same way: the two must
+        // agree to well below T_i c_i for the deep layers, whose gradients are a difference against them).
+#if GSPLAT_TWO_LEVEL
+        v2f Lr = {0.f, 0.f}, Lg = {0.f, 0.f}, Lb = {0.f, 0.f};
+#else
+        v2f& Lr = Cr; v2f& Lg = Cg; v2f& Lb = Cb;
+#endif
         for (int k0 = 0; k0 < maxc; k0 += 16) {
           const int k1 = min(k0 + 16, maxc);
           for (int k = k0; k < k1; k += 2) {
@@ -1375,11 +1397,14 @@ __global__ __launch_bounds__(64) void raster_forward_kernel(const uint2* __restr
             al1.y = (i11 && al1.y >= alpha_cutoff && T.y > 5e-5f) ? al1.y : 0.0f;
             const v2f w1 = al1 * T;
             T = T - al1 * T;
-            Cr += w0 * b0.z; Cg += w0 * b0.w; Cb += w0 * cb0;
-            Cr += w1 * b1.z; Cg += w1 * b1.w; Cb += w1 * cb1;
+            Lr += w0 * b0.z; Lg += w0 * b0.w; Lb += w0 * cb0;
+            Lr += w1 * b1.z; Lg += w1 * b1.w; Lb += w1 * cb1;
           }
           if (!__any(T.x > 5e-5f || T.y > 5e-5f)) break;       // every 16 entries: all pixels dead
         }
+#if GSPLAT_TWO_LEVEL
+        Cr += Lr; Cg += Lg; Cb += Lb;
+#endif
         alive_any = __any(T.x > 5e-5f || T.y > 5e-5f);        // dead pixels stay dead
     }
     if (stats && lane == 0)
@@ -1571,6 +1596,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         ++st_chunks;
         st_visited += (uint32_t)maxc;
         int kdone = 0;                       // iterations executed (uniform): slots [0, kdone) of every queue are valid
+        v2f lpre = {0.f, 0.f};               // sum of w (c . G) over the chunk's entries so far (two-level, as the forward's colour)
         // One queue entry: the group's 16 pixels against one Gaussian; the nine sums go to slot k of the group's queue.
         auto entry = [&](const f4& a, const f4& b, const float cbl, const int k) {
             const float go = b.y;
@@ -1595,10 +1621,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             w.x = alive0 ? w.x : 0.0f; w.y = alive1 ? w.y : 0.0f;
             const v2f sdot = b.z * Gr + b.w * Gg + cbl * Gb;
             const v2f ar = w * Gr, ag = w * Gg, ab = w * Gb;
-            suffix -= w * sdot;                                            // now the sum over k > i
+#if GSPLAT_TWO_LEVEL
+            lpre += w * sdot;
+            const v2f sfx = suffix - lpre;                                 // the sum over k > i
+#else
+            suffix -= w * sdot;
+            const v2f sfx = suffix;
+#endif
             v2f om = 1.0f - al;
             om.x = __builtin_amdgcn_rcpf(om.x); om.y = __builtin_amdgcn_rcpf(om.y);   // 1 - alpha >= 0.01
-            v2f dal = T * sdot - suffix * om;
+            v2f dal = T * sdot - sfx * om;
             // the pixel is alive, alpha passed its two tests, and clamp_max passes the gradient where o g <= alpha_max (render.py:372)
             dal.x = (alive0 && p0 && og.x <= alpha_max) ? dal.x : 0.0f;
             dal.y = (alive1 && p1 && og.y <= alpha_max) ? dal.y : 0.0f;
@@ -1640,6 +1672,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           kdone = k1;
           if (!__any(T.x > 5e-5f || T.y > 5e-5f)) break;          // every 8 entries: all pixels dead
         }
+#if GSPLAT_TWO_LEVEL
+        suffix -= lpre;                                       // (once per chunk)
+#endif
         alive_any = __any(T.x > 5e-5f || T.y > 5e-5f);        // dead pixels stay dead
         __syncthreads();
         {   // entry `lane`: add up the slots of the sub-tiles it was queued in
@@ -2035,6 +2070,8 @@ int gsplat_abi_version(void) { return GSPLAT_ABI_VERSION; }
 // in the product library): register device buffers of lists * 16 bytes each that the raster kernels fill with per-wave
 // statistics; pass NULL to switch the statistics off again.
 void gsplat_debug_set_stats(void* fwd, void* bwd) { g_stats_fwd = (WaveStats*)fwd; g_stats_bwd = (WaveStats*)bwd; }
+// device buffers of n x 8 and n x 4 bytes that the projection kernel fills with the reference's tile rectangle / tile count
+void gsplat_debug_set_ref_rect(void* rect, void* tiles) { g_ref_rect = (u2*)rect; g_ref_tiles = (uint32_t*)tiles; }
 #endif
 
 const char* gsplat_last_error(void) { return g_err; }
@@ -2089,7 +2126,11 @@ int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_vie
     const bool jac = fused && (flags & GSPLAT_PROJECT_SAVE_SH_JACOBIAN) != 0;
     const bool late = (flags & GSPLAT_PROJECT_COUNTS_LATE) != 0 && n > 0;      // counters totalled by bin_count_kernel
     if (n > 0) {
+#ifdef GSPLAT_DIAGNOSTICS
+        Records out{ps.rec, ps.rect, ps.depth, ps.tiles, ps.mask, g_ref_rect, g_ref_tiles};
+#else
         Records out{ps.rec, ps.rect, ps.depth, ps.tiles, ps.mask, nullptr, nullptr};
+#endif
         DevCounts* cm = mapped ? (DevCounts*)counts_host : nullptr;
         CounterBlock* cb = (CounterBlock*)scratch;
         const dim3 grid(blocks64(n)), block(64);

@@ -14,6 +14,8 @@ from tests import util
 
 seed = int(sys.argv[1])
 gs = importlib.import_module("3d-gaussian-splatting-for-novel-view-synthesis_amd")
+if len(sys.argv) > 2 and sys.argv[2] == "det":          # fixed-order sums instead of float atomics (is an error an accumulation error?)
+    gs.set_deterministic(True)
 rng = np.random.default_rng(1000 + seed)
 H, W = int(rng.integers(9, 150)), int(rng.integers(9, 200))
 n = int(rng.integers(1, 1800))

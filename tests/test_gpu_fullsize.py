@@ -56,18 +56,42 @@ def cal3():
                 grads={k: util.grad_errors(g32[k], g64[k]) for k in NAMES})
 
 
-P_KNIFE_EDGE = 8      # (tile, Gaussian) pairs: fp32 rounding of u +- ceil(2.5 sqrt(lambda)) against a tile border (of 2.7 M pairs at
-                      # config 3: two since the projection math is compiled with fp contraction "on", none by luck before; the float64
-                      # oracle itself is off by up to 64, see test_full_frame_parity_vs_c_oracle)
+def _knife_edge_pairs(cfg, ulps=4.0):
+    """How many of the reference's (tile, Gaussian) pairs ANY fp32 evaluation may count differently: the tile rectangle of a
+    Gaussian is u +- r, r = ceil(2.5 sqrt(lambda_max)) (render.py:227-258), and lambda_max comes out of torch.linalg.eigh (LAPACK) in
+    the reference and out of a closed form in the kernel -- a few ulp apart, so r differs by one exactly where 2.5 sqrt(lambda_max)
+    lies within a few ulp of an integer (u, v themselves are the same IEEE operations in both: bit-identical).  Returns the sum
+    over those Gaussians of |tiles(r) - tiles(other r)| from the float64 oracle's projection
+    (profiles/r03_ref_pairs_diff_config3.txt: at config 3 ONE Gaussian, #672304, 0.1 ulp from r = 5 | 6, is what separates the kernel's
+    2 720 510 from the reference's 2 720 508)."""
+    s = scenes.synthetic_scene(cfg)
+    st = {}
+    q = {k: torch.tensor(s[k], dtype=torch.float64) for k in NAMES}
+    tp.render_fused(*[q[k] for k in NAMES], torch.eye(4, dtype=torch.float64), s["H"], s["W"], s["fx"], s["fy"], s["cx"], s["cy"],
+                    stages=st, stop_after_binning=True)
+    lam = st["evals"][:, 1].numpy().clip(1e-12, 1e4)
+    x = 2.5 * np.sqrt(lam)
+    near = np.abs(x - np.round(x)) < ulps * np.spacing(x.astype(np.float32)).astype(np.float64)
+    u, v = st["u"].numpy()[near], st["v"].numpy()[near]
+    H, W, T = s["H"], s["W"], 16
 
-
-def _counts_match(got, ref):
-    return got[0] == ref[0] and abs(got[1] - ref[1]) <= P_KNIFE_EDGE
+    def tiles(r):
+        lo_u, hi_u, lo_v, hi_v = np.floor(u - r), np.floor(u + r), np.floor(v - r), np.floor(v + r)
+        on = (hi_u >= 0) & (lo_u < W) & (hi_v >= 0) & (lo_v < H)
+        tx = np.clip(hi_u, 0, W - 1) // T - np.clip(lo_u, 0, W - 1) // T + 1
+        ty = np.clip(hi_v, 0, H - 1) // T - np.clip(lo_v, 0, H - 1) // T + 1
+        return np.where(on, tx * ty, 0)
+    r_lo = np.round(x[near])               # the integer 2.5 sqrt(lambda) sits next to: r is that integer or the next one
+    return int(np.abs(tiles(r_lo + 1) - tiles(r_lo)).sum()), int(near.sum())
 
 
 def test_config3_counts_match_the_reference(cfg3):
     _, _, _, img, stats = cfg3
-    assert _counts_match(stats[1:], (973_068, 2_720_508)), stats  # measured by running the reference
+    slack, n_near = _knife_edge_pairs(3)
+    print(f"config 3: V {stats[1]}, P {stats[2]} (reference: 973 068, 2 720 508); {n_near} Gaussians within 4 ulp of a radius flip, "
+          f"worth {slack} pairs")
+    assert stats[1] == 973_068, stats                          # measured by running the reference (BASELINE.md §2)
+    assert abs(stats[2] - 2_720_508) <= slack, (stats, slack)
     assert torch.isfinite(img).all() and float(img.min()) >= 0.0 and float(img.max()) <= 1.0
     assert 0.05 < float(img.mean()) < 0.95
 
@@ -171,11 +195,13 @@ def test_full_frame_parity_vs_c_oracle(gs, cfg, counts, cal3):
     # on the same scene -- the whole frame for config 2, the 1920 x 32 window of `cal3` for config 3 (the float32 oracle needs 45 GB
     # and minutes for the whole 1080p frame; flip densities and relative gradient errors carry over from the window).
     img = gs.render_gaussians(*[p[k] for k in NAMES], torch.eye(4, device=DEV), *cam)
-    assert _counts_match(gs.render_stats(img)[1:], counts), gs.render_stats(img)
+    got = gs.render_stats(img)[1:]
+    slack = _knife_edge_pairs(cfg)[0]           # pairs of the Gaussians whose radius ceil() is within fp32's reach of flipping
+    assert got[0] == counts[0] and abs(got[1] - counts[1]) <= slack, (got, counts, slack)
     (img * torch.tensor(w, device=DEV)).sum().backward()
     st, ref, g, (V, P) = c_oracle.render(s, *cam, grad_image=w.astype(np.float64))
-    # the float64 oracle may differ from the fp32 counts in a handful of knife-edge ceil() radii
-    assert st == 0 and V == counts[0] and abs(P - counts[1]) <= 64
+    # the float64 oracle differs from the reference's own fp32 counts in the same knife-edge radii
+    assert st == 0 and V == counts[0] and abs(P - counts[1]) <= slack
     if cfg == 2:
         img32, g32 = _oracle_run(s, torch.eye(4), cam, w, torch.float32)
         cal_img, cal_g = util.image_errors(img32, ref), {k: util.grad_errors(g32[k], g[k]) for k in NAMES}

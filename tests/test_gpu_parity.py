@@ -210,14 +210,14 @@ def test_long_lists_take_the_large_sort_paths(gs, n, longest):
         util.check_grad(p[k].grad.cpu().numpy(), p64[k].grad.numpy(), k, cal=g32[k])
 
 
-def _oracle(s, cam, c2w, w, dtype, z_order_eps=None):
+def _oracle(s, cam, c2w, w, dtype, z_order_eps=None, **kw):
     """(image, gradients) of the oracle evaluated in `dtype` (float32 = the reference's own fp32 arithmetic: the calibration)."""
     q = {k: v.to(dtype) for k, v in s.items()}
     if z_order_eps is not None:            # make (depth, index) the unique order in float64: the HIP path's tie rule
         q["pos"] = q["pos"].clone()
         q["pos"][:, 2] += torch.arange(len(q["pos"]), dtype=dtype) * z_order_eps
     q = {k: v.detach().clone().requires_grad_(True) for k, v in q.items()}
-    img = tp.render_fused(q["pos"], q["f_dc"], q["f_rest"], q["opacity_raw"], q["scale_raw"], q["q_raw"], c2w.to(dtype), *cam)
+    img = tp.render_fused(q["pos"], q["f_dc"], q["f_rest"], q["opacity_raw"], q["scale_raw"], q["q_raw"], c2w.to(dtype), *cam, **kw)
     (img * w.to(dtype)).sum().backward()
     return img.detach().double().numpy(), {k: (v.grad.double().numpy() if v.grad is not None else np.zeros(v.shape)) for k, v in q.items()}
 
@@ -320,7 +320,7 @@ def test_factored_sh_gradient_exchange_matches_the_plain_backward(gs):
     assert (g_rest.cpu().double() - acc[:, 1:, :].transpose(1, 2).reshape(n, 45)).abs().max() < 1e-5
 
 
-@pytest.mark.parametrize("seed", list(range(10)) + list(range(100, 150)))
+@pytest.mark.parametrize("seed", list(range(10)) + list(range(100, 150)) + [207, 339])      # (207, 339: the two of 400 further seeds that round 2 left outside the bounds)
 def test_random_scenes_vs_oracle(gs, seed):
     """Randomised image sizes, cameras, anisotropies and opacities against the float64 oracle: exercises ragged list grids,
     partial coarse bins, masks of thin rotated ellipses, chunk and group boundaries of the binning and raster kernels."""
@@ -353,13 +353,34 @@ def test_random_scenes_vs_oracle(gs, seed):
     (img * w.to(DEV)).sum().backward()
     # every bound beyond SURVEY 8c's is K_CAL x what the oracle in float32 (the reference's own fp32 arithmetic) does on this seed
     img32, g32 = _oracle(t, cam, c2w, w, torch.float32)
-    util.check_image(img.detach().cpu().numpy(), ref.detach().numpy(), cal=img32, what=f"seed {seed} image")
+    known = KNOWN_CORNERS.get(seed, {})
+    util.check_image(img.detach().cpu().numpy(), ref.detach().numpy(), cal=img32, what=f"seed {seed} image", frac=known.get("image_bulk_frac"))
+    band = None
+    if known.get("flip_band"):
+        # float64 gradients with the chi-square clip moved by -+ 1e-4 relative: what flipping the pixels that sit within fp32's
+        # reach of the clip does to every gradient entry (fp32 evaluates q of a needle-shaped Gaussian to ~5e-5 relative)
+        lo = _oracle(t, cam, c2w, w, torch.float64, chi_square_clip=6.25 * (1 - known["flip_band"]))[1]
+        hi = _oracle(t, cam, c2w, w, torch.float64, chi_square_clip=6.25 * (1 + known["flip_band"]))[1]
+        band = {k: np.abs(hi[k] - lo[k]) for k in util.PARAMS}
     for k in util.PARAMS:
         g64 = p64[k].grad.numpy()
         if np.abs(g64).max() > 0:
-            util.check_grad(p[k].grad.cpu().numpy(), g64, k, cal=g32[k])
+            util.check_grad(p[k].grad.cpu().numpy(), g64, k, cal=g32[k], band=None if band is None else band[k])
         else:
             assert float(p[k].grad.abs().max()) == 0.0
+
+
+# The two seeds of 2 x 400 further ones (tests/stress_random_scenes.py, profiles/r02_final_stress400_summary.txt) that lie outside
+# the general bounds, kept here with their cause and their own stated bound:
+#   339  ONE pixel (76, 62) at the far end of a needle-shaped Gaussian (2D eigenvalues 2.7 and 4563, 2.5 sigma = 169 px) has
+#        q = 6.25 within fp32's reach and is inside the clip in float64, outside in the kernel (the float32 oracle happens to keep
+#        it); at the far end of a needle a pixel weighs ~ (169 px)^2 in the second moments, and the rotation gradient of a needle is
+#        the tiny off-diagonal of dL/dcov2d times the eigenvalue gap: 1.5 % of that Gaussian's q_raw gradient
+#        (tools/moments_check.py 339 801).  Bound: the general one outside the band that moving the clip by -+ 1e-4 opens.
+#   207  a 42 x 95 image with 6 of 11 970 values between 1.0e-5 and 1.8e-5 (no flip: q of large thin Gaussians carries ~1e-4
+#        relative noise in fp32 -- terms of ~2000 cancel to <= 6.25 -- which the CPU reference's double-accumulating sums partly
+#        hide).  Bound: bulk fraction 6e-4 at 1e-5, every value below 5e-3 as everywhere.
+KNOWN_CORNERS = {339: {"flip_band": 1e-4}, 207: {"image_bulk_frac": 1 - 6e-4}}
 
 
 def test_render_frames_is_the_frame_by_frame_result(gs):

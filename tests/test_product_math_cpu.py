@@ -221,3 +221,44 @@ def test_pieces_forward_backward(hm):
     util.check_grad(gfd, d["grad_f_dc"], "f_dc", l2=1e-5, mx=1e-5)
     util.check_grad(gfr, d["grad_f_rest"], "f_rest", l2=1e-5, mx=1e-5)
     util.check_grad(gpt, d["grad_points"], "points", l2=1e-5, mx=2e-5)
+
+
+def test_rotation_gradient_of_near_isotropic_gaussians_is_cancellation_free(hm):
+    """dL/dq_raw of Sigma = R D R^T vanishes as the scales approach each other; by the plain chain rule through quat_to_rot it is a
+    difference of terms of size |G| d, and its relative error grows like 1e-7 / |r_i - r_j| (the reference's own fp32 autograd
+    has exactly that: 1e-4 at a log-scale spread of 1e-3).  cov_from_params_backward forms it from the torque
+    2 G'_ij (d_i - d_j), d_i - d_j = d_j expm1(2 (r_i - r_j)): accurate to fp32 rounding at every spread, and still the chain rule's
+    value where |q_raw| is as small as the reference's eps."""
+    rng = np.random.default_rng(0)
+    n = 4000
+    for spread, bound in ((0.3, 2e-6), (1e-2, 2e-6), (1e-3, 1e-5), (1e-4, 1e-4)):
+        sr = (rng.normal(-2, 0.5, (n, 1)) + rng.normal(0, 1, (n, 3)) * spread).astype(np.float32)
+        qr = rng.normal(0, 1, (n, 4)).astype(np.float32)
+        w = rng.normal(0, 1, (n, 3, 3)).astype(np.float32)
+        a = torch.tensor(sr, dtype=torch.float64, requires_grad=True)
+        b = torch.tensor(qr, dtype=torch.float64, requires_grad=True)
+        (tp.covariance_from_params(a, b) * torch.tensor(w, dtype=torch.float64)).sum().backward()
+        gs, gq = np.zeros_like(sr), np.zeros_like(qr)
+        hm.hm_build_sigma_backward(C.c_int64(n), _ptr(sr), _ptr(qr), _ptr(w), _ptr(gs), _ptr(gq))
+        ref = b.grad.numpy()
+        err = np.linalg.norm(gq - ref) / np.linalg.norm(ref)
+        assert err <= bound, (spread, err)
+        assert np.linalg.norm(gs - a.grad.numpy()) / np.linalg.norm(a.grad.numpy()) <= 1e-6
+    # tiny quaternions: the normalisation's eps matters, R(q) is no rotation -> the chain-rule branch, same values as autograd
+    qr = (rng.normal(0, 1, (n, 4)) * 1e-6).astype(np.float32)
+    sr = rng.normal(-2, 0.5, (n, 3)).astype(np.float32)
+    a = torch.tensor(sr, dtype=torch.float64, requires_grad=True)
+    b = torch.tensor(qr, dtype=torch.float64, requires_grad=True)
+    (tp.covariance_from_params(a, b) * torch.tensor(w, dtype=torch.float64)).sum().backward()
+    gs, gq = np.zeros_like(sr), np.zeros_like(qr)
+    hm.hm_build_sigma_backward(C.c_int64(n), _ptr(sr), _ptr(qr), _ptr(w), _ptr(gs), _ptr(gq))
+    assert np.linalg.norm(gq - b.grad.numpy()) / np.linalg.norm(b.grad.numpy()) <= 1e-5
+    # clamped scales (exp(scale_raw) < 1e-6): differences of the clamped values
+    sr = rng.normal(-14.5, 0.6, (n, 3)).astype(np.float32)
+    qr = rng.normal(0, 1, (n, 4)).astype(np.float32)
+    a = torch.tensor(sr, dtype=torch.float64, requires_grad=True)
+    b = torch.tensor(qr, dtype=torch.float64, requires_grad=True)
+    (tp.covariance_from_params(a, b) * torch.tensor(w, dtype=torch.float64)).sum().backward()
+    gs, gq = np.zeros_like(sr), np.zeros_like(qr)
+    hm.hm_build_sigma_backward(C.c_int64(n), _ptr(sr), _ptr(qr), _ptr(w), _ptr(gs), _ptr(gq))
+    assert np.linalg.norm(gq - b.grad.numpy()) / np.linalg.norm(b.grad.numpy()) <= 1e-4
