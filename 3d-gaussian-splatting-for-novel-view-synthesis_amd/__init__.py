@@ -12,7 +12,8 @@ plus the fused entry `render_gaussians` and the data-parallel helpers in `.dp`.
 """
 from .ops import (HARMONICS, build_sigma_from_params, evaluate_sh, inv2x2, project_points, quat_to_rotmat, render,
                   render_frames, render_gaussians, render_stats, scale_intrinsics, deferred_checks, run_deferred, set_deterministic,
-                  PairCapacityExceeded)
+                  PairCapacityExceeded, binned_pairs, reset_pair_capacity)
+from . import ops  # noqa: E402,F401
 
 from . import losses  # noqa: E402,F401  (L1 + SSIM loss)
 from .losses import compute_loss  # noqa: E402,F401
@@ -26,5 +27,5 @@ from . import training  # noqa: E402,F401  (one training iteration of the refere
 __all__ = [
     'build_sigma_from_params', 'quat_to_rotmat', 'evaluate_sh', 'HARMONICS', 'render', 'project_points', 'inv2x2',
     'scale_intrinsics', 'render_gaussians', 'render_stats', 'render_frames', 'deferred_checks', 'run_deferred', 'set_deterministic',
-    'PairCapacityExceeded',
+    'PairCapacityExceeded', 'binned_pairs', 'reset_pair_capacity',
 ]

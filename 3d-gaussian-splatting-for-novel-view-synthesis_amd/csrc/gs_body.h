@@ -15,10 +15,11 @@ struct u2 { uint32_t x, y; };
 
 // Projected record: ONE 64-byte line per Gaussian (the rasterizer gathers records by id; three separate 16-byte
 // streams cost three cache lines per gather), plus small per-Gaussian streams for the binning kernels:
-//   rec[i] = { (u, v, A11, A12), (A22, opacity, ex, ey), (r, g, b, depth z), (unused) }
+//   rec[i] = { (u, v, A11, A12), (A22, opacity, ex, ey), (r, g, b, depth z), (row-span constants of a large Gaussian) }
 //   rect[i] = (bx0 | by0 << 16, bx1 | by1 << 16)   inclusive rectangle of lists (16 x 8 pixels each) binned
 //   depth[i] = z                                   tiles[i] = lists touched (0 = contributes to no pixel)
-//   mask[i]: bit k = the ellipse {q <= chi} touches list k of the rectangle (row-major; all ones for rectangles > 32 lists)
+//   mask[i]: bit k = the ellipse {q <= chi} touches list k of the rectangle (row-major; all ones for rectangles > 32 lists, whose
+//            lists are the row spans of gs_math.h big_row_span instead: tiles[i] counts those)
 //   ref_rect[i] (host check only) = the reference's own tile rectangle (F10), T x T tiles
 // (ex, ey) are the half-extents of {q <= chi_square_clip}: the rasterizer culls with them at staging time.
 struct alignas(64) Rec64 { f4 r0, r1, r2, pad; };
@@ -44,6 +45,7 @@ GS_HD ViewK make_viewk(const gsplat_view& v) {
     k.gb = (float)((double)v.H + (double)v.pix_guard - (double)v.cy);
     k.opacity_min = (float)((double)v.alpha_cutoff * 0.5);
     k.min_conis = v.min_conis; k.chi_clip = v.chi_square_clip; k.alpha_max = v.alpha_max; k.alpha_cutoff = v.alpha_cutoff;
+    k.chi_pad = (float)((double)v.chi_square_clip * 1.001 + 1e-4);
     k.H = v.H; k.W = v.W; k.tile = v.tile;
     k.tiles_x = (v.W + v.tile - 1) / v.tile; k.tiles_y = (v.H + v.tile - 1) / v.tile;
     k.lists_x = (v.W + LIST_W - 1) / LIST_W; k.lists_y = (v.H + LIST_H - 1) / LIST_H;
@@ -72,7 +74,7 @@ struct GaussIn {
 };
 
 struct RecOut {             // what K1 stores for one Gaussian
-    f4 r0, r1, r2;
+    f4 r0, r1, r2, r3;      // r3: the row-span constants of a large Gaussian (gs_math.h big_span_constants), else zeros
     u2 rect;                // binned lists
     uint32_t tiles;         // number of lists
     uint32_t mask;          // which lists of the rectangle (see Records)
@@ -109,7 +111,7 @@ GS_HD RecOut project_finish(const GaussIn& in, const Proj& o, bool fused, Coef c
     r.vis = o.vis;
     r.tiles = 0;
     r.mask = 0u;
-    r.r0 = r.r1 = r.r2 = f4{0.f, 0.f, 0.f, 0.f};
+    r.r0 = r.r1 = r.r2 = r.r3 = f4{0.f, 0.f, 0.f, 0.f};
     r.rect = u2{0u, 0u};
     r.ref_rect = u2{0u, 0u};
     r.ref_tiles = 0;
@@ -130,11 +132,12 @@ GS_HD RecOut project_finish(const GaussIn& in, const Proj& o, bool fused, Coef c
         if (o.bx1 >= o.bx0 && o.by1 >= o.by0) {
             const uint32_t area = (uint32_t)((o.bx1 - o.bx0 + 1) * (o.by1 - o.by0 + 1));
             r.mask = o.bmask;
-            r.tiles = area > 32u ? area : (uint32_t)__builtin_popcount(r.mask);
+            r.tiles = area > 32u ? (uint32_t)o.btiles : (uint32_t)__builtin_popcount(r.mask);
         }
         r.r0 = f4{o.u, o.v, o.A11, o.A12};
         r.r1 = f4{o.A22, o.opacity, o.ex, o.ey};
         r.r2 = f4{rgb[0], rgb[1], rgb[2], o.z};
+        r.r3 = f4{o.bk4[0], o.bk4[1], o.bk4[2], o.bk4[3]};
         if (r.tiles) r.rect = u2{(uint32_t)o.bx0 | ((uint32_t)o.by0 << 16), (uint32_t)o.bx1 | ((uint32_t)o.by1 << 16)};
     }
     return r;
@@ -219,7 +222,7 @@ GS_HD int project_one(int64_t i, const gsplat_gaussians& g, bool fused, Coef coe
                       const Records& out) {
     const RecOut r = project_core(load_gauss_global(i, g, fused), fused, coef, cam, vk);
     if (r.vis == VIS_OK) {
-        out.rec[i].r0 = r.r0; out.rec[i].r1 = r.r1; out.rec[i].r2 = r.r2;
+        out.rec[i].r0 = r.r0; out.rec[i].r1 = r.r1; out.rec[i].r2 = r.r2; out.rec[i].pad = r.r3;
         out.rect[i] = r.rect; out.depth[i] = r.r2.w; out.mask[i] = r.mask;
         if (out.ref_rect) out.ref_rect[i] = r.ref_rect;
     }

@@ -41,6 +41,8 @@ struct ViewK {
     float gl, gr, gt, gb;       // guard-band bounds: -g-cx, W+g-cx, -g-cy, H+g-cy (utils.py:82-91)
     float opacity_min;          // alpha_cutoff * 0.5 (render.py:107)
     float min_conis, chi_clip, alpha_max, alpha_cutoff;
+    float chi_pad;              // chi_clip * 1.001 + 1e-4, rounded ONCE on the host: every kernel that enumerates the row spans of a large
+                                // Gaussian (projection, binning, deterministic backward) must see the same float
     int32_t H, W, tiles_x, tiles_y, tile;     // tile = the reference's T (render.py:62): only F10/F11's rectangle and pair count use it
     int32_t lists_x, lists_y;                 // grid of LIST_W x LIST_H-pixel lists: what is actually binned and rasterised
 };
@@ -319,6 +321,8 @@ struct Proj {
     int tx0, ty0, tx1, ty1;       // inclusive tile rectangle of the reference (F10/F11: square 2.5-sigma AABB, T x T tiles)
     int bx0, by0, bx1, by1;       // inclusive rectangle actually binned: tight box, in 16 x 8-pixel lists (empty: bx1 < bx0)
     uint32_t bmask;               // which lists of that rectangle the ellipse can touch (binned_mask)
+    int btiles;                   // rectangles of more than 32 lists: lists the ellipse can touch, row by row (big_row_span)
+    float bk4[4];                 // ... and the constants of those spans (big_span_constants), kept in the record
     int vis;                      // VIS_*
 };
 
@@ -338,8 +342,55 @@ GS_HD bool ellipse_touches_rect(const Proj& o, float chi_pad, float r12_22, floa
     return !(fminf(qx, qy) > chi_pad);          // NaN -> true
 }
 
+// Rectangles of more than 32 lists (large Gaussians) have no mask; their lists are enumerated ROW BY ROW instead: which lists of
+// row y (pixel rows y LIST_H .. y LIST_H + LIST_H - 1) does {q <= chi_pad} reach?  The region is convex, so inside a horizontal band
+// it projects onto ONE x-interval [lo, hi]: with c = -A12 / A11 the curve's right side is x_hi(t) = c t + sqrt(chi / A11 - D t^2 / A11^2)
+// (concave in t = dv, maximal = +ex at t = -(A12 / A22) ex), the left side x_lo(t) = c t - sqrt(..) (convex, minimal = -ex at the
+// mirrored t): over the band's part [t0, t1] of the ellipse's dv-range the extreme is that stationary value if its t lies inside,
+// else the larger (smaller) endpoint value.  Conservative like the list test (same padded chi, + 0.02 px); lists hold pixel CENTRES
+// x LIST_W .. x LIST_W + LIST_W - 1.  Returns an empty span (xa > xb) for a row the ellipse misses.  Non-PD conic: the whole row.
+struct RowSpan { int xa, xb; };
+struct BigSpanK {               // per-Gaussian constants of big_row_span
+    float u, v, ex, ey;         // centre; half-extents of {q <= chi} (the record's: Proj::ex, ey)
+    float c, k0, k1, ts;        // c = -A12 / A11, k0 = chi_pad / A11, k1 = D / A11^2, ts = (A12 / A22) ex;  k0 < 0: the conic is not PD
+    int bx0, bx1;
+};
+// (the projection kernel computes the four derived constants once and leaves them in the record's spare 16 bytes: the binning
+//  kernels enumerate a large Gaussian's rows three times and would otherwise repeat four divisions each time)
+GS_HD void big_span_constants(float A11, float A12, float A22, float ex, float chi_pad, float out[4]) {
+    const float D = A11 * A22 - A12 * A12;
+    const bool pd = (D > 0.f) && (A11 > 0.f) && (A22 > 0.f) && (ex < 1e30f);
+    out[0] = -A12 / A11; out[1] = pd ? chi_pad / A11 : -1.f; out[2] = D / (A11 * A11); out[3] = (A12 / A22) * ex;
+}
+GS_HD BigSpanK big_span_setup(float u, float v, float ex, float ey, const float k4[4], int bx0, int bx1) {
+    BigSpanK k;
+    k.u = u; k.v = v; k.ex = ex; k.ey = ey; k.c = k4[0]; k.k0 = k4[1]; k.k1 = k4[2]; k.ts = k4[3]; k.bx0 = bx0; k.bx1 = bx1;
+    return k;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GS_SQRT_FAST(x) __builtin_amdgcn_sqrtf(x)      // v_sqrt_f32 (1 ulp): the spans are padded by 0.02 px, and every kernel uses the same one
+#else
+#define GS_SQRT_FAST(x) sqrtf(x)
+#endif
+GS_HD RowSpan big_row_span(const BigSpanK& k, int y) {
+    if (!(k.k0 >= 0.f)) return RowSpan{k.bx0, k.bx1};
+    const float d0 = (float)(y * LIST_H) - k.v - 0.02f, d1 = (float)(y * LIST_H + LIST_H - 1) - k.v + 0.02f;
+    if (d0 > k.ey || d1 < -k.ey) return RowSpan{1, 0};
+    const float t0 = fmaxf(d0, -k.ey), t1 = fminf(d1, k.ey);
+    const float r0 = GS_SQRT_FAST(fmaxf(k.k0 - k.k1 * t0 * t0, 0.f)), r1 = GS_SQRT_FAST(fmaxf(k.k0 - k.k1 * t1 * t1, 0.f));
+    float hi = fmaxf(k.c * t0 + r0, k.c * t1 + r1), lo = fminf(k.c * t0 - r0, k.c * t1 - r1);
+    if (-k.ts >= t0 && -k.ts <= t1) hi = k.ex;
+    if (k.ts >= t0 && k.ts <= t1) lo = -k.ex;
+    hi = fminf(hi, k.ex); lo = fmaxf(lo, -k.ex);
+    const float pad = 0.02f + 1e-4f * k.ex;
+    // smallest list whose last pixel centre is >= u + lo - pad, largest whose first is <= u + hi + pad
+    const float fa = ceilf((k.u + lo - pad - (float)(LIST_W - 1)) * (1.0f / LIST_W)), fb = floorf((k.u + hi + pad) * (1.0f / LIST_W));
+    const int xa = (int)fmaxf(fa, (float)k.bx0), xb = (int)fminf(fb, (float)k.bx1);
+    return RowSpan{xa, xb};
+}
+
 // Bit k (row-major inside the binned rectangle) = the Gaussian can touch list k.  Rectangles of more than 32 lists are
-// not refined (all ones).
+// not refined (all ones): their lists are counted and enumerated row by row (big_row_span).
 GS_HD uint32_t binned_mask(const Proj& o, const ViewK& vk) {
     if (o.bx1 < o.bx0 || o.by1 < o.by0) return 0u;
     const int w = o.bx1 - o.bx0 + 1, h = o.by1 - o.by0 + 1;
@@ -359,7 +410,8 @@ GS_HD void project_gaussian(const float p[3], const float S[6], float o_raw, con
                             ProjMid& m) {
     o.vis = VIS_CULLED;
     o.tx0 = o.ty0 = 0; o.tx1 = o.ty1 = -1;
-    o.bx0 = o.by0 = 0; o.bx1 = o.by1 = -1; o.bmask = 0u;
+    o.bx0 = o.by0 = 0; o.bx1 = o.by1 = -1; o.bmask = 0u; o.btiles = 0;
+    o.bk4[0] = o.bk4[1] = o.bk4[2] = o.bk4[3] = 0.f;
     // F4 opacity prefilter
     m.sg = sigmoidf_(o_raw);
     o.opacity = clampf_(m.sg, 0.f, 0.999f);
@@ -471,6 +523,16 @@ GS_HD void project_gaussian(const float p[3], const float S[6], float o_raw, con
             o.by0 = (int)clampf_(lo_v, 0.f, hm) / LIST_H;
             o.by1 = (int)clampf_(hi_v, 0.f, hm) / LIST_H;
             o.bmask = binned_mask(o, vk);
+            const int w = o.bx1 - o.bx0 + 1, h = o.by1 - o.by0 + 1;
+            o.btiles = 0;
+            if (w * h > 32) {            // a large Gaussian: its lists row by row (what bin_count / bin_scatter enumerate)
+                big_span_constants(o.A11, o.A12, o.A22, o.ex, vk.chi_pad, o.bk4);
+                const BigSpanK bk = big_span_setup(o.u, o.v, o.ex, o.ey, o.bk4, o.bx0, o.bx1);
+                for (int y = o.by0; y <= o.by1; ++y) {
+                    const RowSpan sp = big_row_span(bk, y);
+                    if (sp.xb >= sp.xa) o.btiles += sp.xb - sp.xa + 1;
+                }
+            }
         }
     }
 }

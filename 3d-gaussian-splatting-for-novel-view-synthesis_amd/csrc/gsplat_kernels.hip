@@ -92,7 +92,8 @@ struct ProjectState {
     float* depth;
     uint32_t* tiles;         // per Gaussian: number of lists (0 = contributes nowhere)
     uint32_t* mask;          // per Gaussian: which lists of the rectangle (ellipse / list test; all ones above 32 lists)
-    uint32_t* bin_total;     // [bins] pairs per coarse bin
+    uint32_t* bin_total;     // [3 x bins] pairs per coarse bin of the small Gaussians | of the large ones (rectangles of more than 32
+                             //            lists: bin_total + bins) | the large ones' scatter cursor (bin_total + 2 bins); zero per frame
     uint32_t* bin_start;     // [bins + 1] exclusive prefix of bin_total
     uint32_t* block_off;     // [blocks x bins] where a block's pairs start inside a bin
     uint32_t* list_count;    // [bins x 64] pairs per list (split_count_kernel)
@@ -100,6 +101,8 @@ struct ProjectState {
     uint32_t* order;         // [lists] launch order: longest list first
     uint32_t* class_bounds;  // [8] boundaries of the sort size classes inside `order`
     float* kj;               // [n][12] fused inputs, GSPLAT_PROJECT_SAVE_SH_JACOBIAN: d rgb / d logit (3), d logit / d position (9)
+    uint32_t* big_flag;      // [ceil(n / 64)] does this wave of the projection kernel hold a large Gaussian (rectangle of more than 32
+                             // lists)?  written by EVERY wave in every frame: the binning kernels' big blocks look here before anything else
     int64_t bytes;
 };
 
@@ -119,7 +122,7 @@ ProjectState carve_project(void* base, int64_t n, int64_t nl) {
     s.depth = (float*)(p + o); o += up(n * 4);
     s.tiles = (uint32_t*)(p + o); o += up(n * 4);
     s.mask = (uint32_t*)(p + o); o += up(n * 4);
-    s.bin_total = (uint32_t*)(p + o); o += up(nb * 4);
+    s.bin_total = (uint32_t*)(p + o); o += up(3 * nb * 4);
     s.bin_start = (uint32_t*)(p + o); o += up((nb + 1) * 4);
     s.block_off = (uint32_t*)(p + o); o += up(n_bin_blocks(n) * nb * 4);
     s.list_count = (uint32_t*)(p + o); o += up((nb << BIN_SHIFT) * 4);
@@ -127,6 +130,7 @@ ProjectState carve_project(void* base, int64_t n, int64_t nl) {
     s.order = (uint32_t*)(p + o); o += up(nl * 4);
     s.class_bounds = (uint32_t*)(p + o); o += up(8 * 4);
     s.kj = (float*)(p + o); o += up(n * 48);
+    s.big_flag = (uint32_t*)(p + o); o += up(((n + 255) / 256 * 4) * 4);      // (padded to whole ranges of 256 Gaussians: 16-byte reads)
     s.bytes = o;
     return s;
 }
@@ -286,29 +290,47 @@ __device__ __forceinline__ void stage_geometry(ProjectLds<FUSED>& s, const gspla
     }
 }
 
-// Calls f(list, ordinal, a, b) for every list of a Gaussian's rectangle whose mask bit is set (row-major;
-// ordinal 0 .. nt - 1 counts the calls; a, b = the owning lane's values).  Rectangles of up to 32 lists: each lane walks
-// its own; larger ones (huge Gaussians: up to 32 x 64 lists; never masked) are walked by the whole wave, one after the
-// other.  Call with all 64 lanes active.
+__device__ __forceinline__ bool rect_is_big(u2 rect) {
+    const int w = (int)(rect.y & 0xFFFF) - (int)(rect.x & 0xFFFF) + 1, h = (int)(rect.y >> 16) - (int)(rect.x >> 16) + 1;
+    return w * h > 32;
+}
+
+// Calls f(list, ordinal, a, b) for every list of a Gaussian's rectangle whose mask bit is set (row-major; ordinal 0 .. nt - 1
+// counts the calls; a, b = the owning lane's values).  Rectangles of up to 32 lists only: each lane walks its own.  Larger ones
+// (large Gaussians) are walked row by row by whole waves: for_each_big_row.
 template <class F>
 __device__ __forceinline__ void for_each_list(u2 rect, uint32_t nt, uint32_t mask, int lists_x, int lane, uint64_t a, uint32_t b, F f) {
     const int x0 = rect.x & 0xFFFF, y0 = rect.x >> 16, x1 = rect.y & 0xFFFF, y1 = rect.y >> 16;
-    const bool big = nt > 32u;
-    if (nt && !big) {
+    if (nt && !rect_is_big(rect)) {
         uint32_t k = 0, m = mask;
         for (int y = y0; y <= y1; ++y)
             for (int x = x0; x <= x1; ++x, m >>= 1)
                 if (m & 1u) f((uint32_t)(y * lists_x + x), k++, a, b);
     }
+    (void)lane;
+}
+
+// The lists of the LARGE Gaussians held by the lanes of one wave (`big`: rectangle of more than 32 lists and binned at all), one
+// Gaussian after the other, the lanes taking the ROWS of its rectangle: f(first list of the row's span, lists in the span, payload)
+// per non-empty row (gs_math.h big_row_span: the same spans the projection kernel counted into tiles[]).  Call with all 64 lanes.
+template <class F>
+__device__ __forceinline__ void for_each_big_row(bool big, u2 rect, f4 uvexy, f4 k4, uint64_t payload, int lists_x, int lane, F f) {
     unsigned long long m = __ballot(big);
     while (m) {
         const int src = __ffsll((long long)m) - 1;
         m &= m - 1;
-        const int sx0 = __shfl(x0, src), sy0 = __shfl(y0, src), sx1 = __shfl(x1, src);
-        const int cnt = (int)__shfl((int)nt, src), w = sx1 - sx0 + 1;
-        const uint64_t sa = ((uint64_t)(uint32_t)__shfl((int)(a >> 32), src) << 32) | (uint32_t)__shfl((int)(uint32_t)a, src);
-        const uint32_t sb = (uint32_t)__shfl((int)b, src);
-        for (int k = lane; k < cnt; k += 64) f((uint32_t)((sy0 + k / w) * lists_x + sx0 + k % w), (uint32_t)k, sa, sb);
+#define RL_F(x) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src))
+        const uint32_t rx = (uint32_t)__builtin_amdgcn_readlane((int)rect.x, src), ry = (uint32_t)__builtin_amdgcn_readlane((int)rect.y, src);
+        const float kk[4] = {RL_F(k4.x), RL_F(k4.y), RL_F(k4.z), RL_F(k4.w)};
+        const uint64_t pl = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(payload >> 32), src) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)payload, src);
+        const int x0 = rx & 0xFFFF, y0 = rx >> 16, x1 = ry & 0xFFFF, y1 = ry >> 16;
+        const BigSpanK bk = big_span_setup(RL_F(uvexy.x), RL_F(uvexy.y), RL_F(uvexy.z), RL_F(uvexy.w), kk, x0, x1);
+#undef RL_F
+        for (int y = y0 + lane; y <= y1; y += 64) {
+            const RowSpan sp = big_row_span(bk, y);
+            if (sp.xb >= sp.xa) f((uint32_t)(y * lists_x + sp.xa), (uint32_t)(sp.xb - sp.xa + 1), pl);
+        }
     }
 }
 
@@ -330,7 +352,8 @@ __device__ __forceinline__ void for_each_list(u2 rect, uint32_t nt, uint32_t mas
 template <bool FUSED, bool COLOUR, bool JAC = false, bool TOTALS = true>
 __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const float* __restrict__ c2w, Camera* __restrict__ cam_out, ViewK vk,
                                                      Records out, CounterBlock* cb, DevCounts* counts, DevCounts* counts_mapped,
-                                                     uint32_t* __restrict__ bin_total, int nb, float* __restrict__ kj_out) {
+                                                     uint32_t* __restrict__ bin_total, int nb, float* __restrict__ kj_out,
+                                                     uint32_t* __restrict__ big_flag) {
     // DIRECT (fused inputs with the colour inside): the 44 bytes of geometry per Gaussian are loaded by the lanes themselves (rows
     // of 3 / 4 floats coalesce well enough) and only the 180 bytes of f_rest go through LDS: 11 520 B per wave instead of
     // 15 104 -> 12 waves per CU instead of 10, and the geometry math starts while the coefficients are still arriving.
@@ -367,7 +390,7 @@ __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const f
         build_camera(m, cam);
         if (blockIdx.x == 0 && lane == 0) *cam_out = cam;
     }
-    for (int b = blockIdx.x * 64 + lane; b < nb; b += gridDim.x * 64) bin_total[b] = 0u;
+    for (int b = blockIdx.x * 64 + lane; b < 3 * nb; b += gridDim.x * 64) bin_total[b] = 0u;     // (+ the large Gaussians' totals and cursor)
     if (!DIRECT) __syncthreads();
     Proj o;
     o.vis = VIS_CULLED;
@@ -387,7 +410,7 @@ __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const f
     if (i < g.n) {
         if (r.vis == VIS_OK) {
             Rec64 line;
-            line.r0 = r.r0; line.r1 = r.r1; line.r2 = r.r2; line.pad = f4{0.f, 0.f, 0.f, 0.f};
+            line.r0 = r.r0; line.r1 = r.r1; line.r2 = r.r2; line.pad = r.r3;
             out.rec[i] = line;                   // 64 contiguous bytes per lane, 4 KB per wave
             out.rect[i] = r.rect;
             out.depth[i] = r.r2.w;
@@ -404,6 +427,10 @@ __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const f
         if (out.ref_rect) out.ref_rect[i] = r.ref_rect;
         if (out.ref_tiles) out.ref_tiles[i] = r.vis == VIS_OK ? r.ref_tiles : 0u;
 #endif
+    }
+    {
+        const bool any_large = __any(r.tiles != 0u && rect_is_big(r.rect));
+        if (lane == 0) big_flag[blockIdx.x] = any_large ? 1u : 0u;
     }
     const unsigned long long surv = __ballot(o.vis != VIS_CULLED);
     const unsigned long long seen = __ballot(o.vis == VIS_OK);
@@ -551,13 +578,94 @@ __device__ __forceinline__ void for_block_pairs(const BlockPairs& bp, int lists_
     for (int k = 0; k < BlockPairs::K; ++k) for_each_list(bp.r[k], bp.nt[k], bp.mk[k], lists_x, lane, bp.payload[k], 0u, f);
 }
 
+// What a big block (256 Gaussians, see bin_count_kernel) holds per thread.  Returns false (uniformly) when the block's range has no
+// large Gaussian: the block then leaves -- at config 3 (none at all) that is all these blocks ever do.
+struct BigLane { bool big; u2 rect; f4 uvexy, k4; uint64_t payload; };      // centre + extents, row-span constants (record)
+__device__ __forceinline__ bool load_big_lane(int64_t i, int64_t n, const u2* __restrict__ rect, const uint32_t* __restrict__ tiles,
+                                              const Rec64* __restrict__ rec, const float* __restrict__ depth, BigLane& b,
+                                              const uint32_t* __restrict__ big_flag) {
+    {   // the four projection waves of this range (one uniform 16-byte load): nothing large -> nothing else is even loaded
+        const uint4 f = *reinterpret_cast<const uint4*>(big_flag + (i - threadIdx.x) / 64);
+        if (!(f.x | f.y | f.z | f.w)) return false;
+    }
+    b.rect = u2{0u, 0u};
+    b.big = false;
+    if (i < n) {
+        const uint32_t nt = tiles[i];
+        b.rect = rect[i];                                  // (stale for a Gaussian that is not binned: nt = 0)
+        b.big = nt != 0u && rect_is_big(b.rect);
+    }
+    if (!__syncthreads_or(b.big)) return false;
+    b.uvexy = b.k4 = f4{0.f, 0.f, 0.f, 0.f};
+    b.payload = 0ull;
+    if (b.big) {
+        const Rec64* r = rec + i;
+        const f4 q0 = r->r0, q1 = r->r1;
+        b.uvexy = f4{q0.x, q0.y, q1.z, q1.w};
+        b.k4 = r->pad;
+        b.payload = ((uint64_t)f2u(depth ? depth[i] : 0.f) << 32) | (uint64_t)(uint32_t)i;
+    }
+    return true;
+}
+
+// Does ANY of the ranges this big block will visit (first, first + stride, ...) hold a large Gaussian?  Thread t looks at the t-th of
+// them: one round trip for up to 256 ranges, and a block with nothing to do -- every one of them at config 3 -- leaves after it.
+__device__ __forceinline__ bool any_big_range(const uint32_t* __restrict__ big_flag, int64_t first, int64_t stride, int64_t ranges) {
+    bool has = false;
+    for (int64_t r = first + (int64_t)threadIdx.x * stride; r < ranges; r += 256 * stride) {
+        const uint4 f = *reinterpret_cast<const uint4*>(big_flag + r * 4);
+        has |= (f.x | f.y | f.z | f.w) != 0u;
+    }
+    return __syncthreads_or(has);
+}
+
+// pieces of a run of consecutive lists [l0, l0 + cnt) by coarse bin: g(bin, first list of the piece, lists in the piece)
+template <class G>
+__device__ __forceinline__ void for_bin_pieces(uint32_t l0, uint32_t cnt, G g) {
+    const uint32_t l1 = l0 + cnt - 1u;
+    for (uint32_t b = l0 >> BIN_SHIFT; b <= (l1 >> BIN_SHIFT); ++b) {
+        const uint32_t a = max(l0, b << BIN_SHIFT), e = min(l1, (b << BIN_SHIFT) + (1u << BIN_SHIFT) - 1u);
+        g(b, a, e - a + 1u);
+    }
+}
+
+__device__ __forceinline__ void bin_count_big(int64_t n, const u2* __restrict__ rect, const uint32_t* __restrict__ tiles, int lists_x, int nb,
+                                                        uint32_t* __restrict__ bin_total, const Rec64* __restrict__ rec,
+                                                        const uint32_t* __restrict__ big_flag, uint32_t small_blocks, uint32_t* hist) {
+    const int tid = threadIdx.x;
+    const int64_t ranges = (n + 255) / 256;
+    if (!any_big_range(big_flag, blockIdx.x - small_blocks, gridDim.x - small_blocks, ranges)) return;
+    for (int64_t range = blockIdx.x - small_blocks; range < ranges; range += gridDim.x - small_blocks) {
+        BigLane bl;
+        if (!load_big_lane(range * 256 + tid, n, rect, tiles, rec, nullptr, bl, big_flag)) continue;
+        for (int b = tid; b < nb; b += 256) hist[b] = 0u;
+        __syncthreads();
+        for_each_big_row(bl.big, bl.rect, bl.uvexy, bl.k4, 0ull, lists_x, tid & 63, [&](uint32_t l0, uint32_t cnt, uint64_t) {
+            for_bin_pieces(l0, cnt, [&](uint32_t b, uint32_t, uint32_t c) { atomicAdd(&hist[b], c); });
+        });
+        __syncthreads();
+        for (int b = tid; b < nb; b += 256) {
+            const uint32_t c = hist[b];
+            if (c) atomicAdd(&bin_total[nb + b], c);           // (no offset is drawn here: bin_scatter_kernel's big blocks draw theirs)
+        }
+        __syncthreads();                                       // hist is cleared again by the next range
+    }
+}
+
+// Grid = the blocks of 2048 Gaussians, which bin the SMALL Gaussians (rectangles of up to 32 lists, each lane walking its own), then
+// `big_blocks` blocks of 256 Gaussians, which bin the LARGE ones wave-cooperatively (for_each_big_row): a Gaussian of a trained
+// scene covers hundreds of lists, and 2048 of them per block left the chip with 49 workgroups walking half a million lists each.
 __global__ __launch_bounds__(256) void bin_count_kernel(int64_t n, const u2* __restrict__ rect, const uint32_t* __restrict__ tiles,
                                                         const uint32_t* __restrict__ mask, int lists_x, int nb, uint32_t* __restrict__ bin_total,
                                                         uint32_t* __restrict__ block_off, uint32_t* __restrict__ list_count,
                                                         uint2* __restrict__ ranges, int nl, CounterBlock* cb, DevCounts* counts,
-                                                        DevCounts* counts_mapped) {
+                                                        DevCounts* counts_mapped, const Rec64* __restrict__ rec, const uint32_t* __restrict__ big_flag, uint32_t small_blocks) {
     __shared__ uint32_t hist[MAX_BINS];
     const int tid = threadIdx.x;
+    if (blockIdx.x >= small_blocks) {            // ---- ranges of 256 Gaussians (grid-stride): the large ones of each range
+        bin_count_big(n, rect, tiles, lists_x, nb, bin_total, rec, big_flag, small_blocks, hist);
+        return;
+    }
     const BlockPairs bp = load_block_pairs(n, rect, tiles, mask, nullptr);
     if (cb && blockIdx.x == 0) {                 // GSPLAT_PROJECT_COUNTS_LATE: totals of the projection's sharded counters; shards cleared
         static_assert(COUNT_SHARDS == 256, "one shard per thread");
@@ -598,7 +706,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(int64_t n, const u2* __r
             if (counts_mapped) *counts_mapped = c;
         }
     }
-    for (int l = blockIdx.x * 256 + tid; l < (nb << BIN_SHIFT); l += gridDim.x * 256) {     // for the split kernels
+    for (int l = blockIdx.x * 256 + tid; l < (nb << BIN_SHIFT); l += (int)small_blocks * 256) {     // for the split kernels
         list_count[l] = 0u;
         if (l < nl) ranges[l] = uint2{0u, 0u};
     }
@@ -615,39 +723,156 @@ __global__ __launch_bounds__(256) void bin_count_kernel(int64_t n, const u2* __r
 // bin_scatter_kernel: the same enumeration; a pair goes to bin_start[bin] + the block's offset in the bin + its arrival
 // rank inside the block (LDS atomic).  The order inside a bin is arbitrary; the per-list sort by the unique payload makes
 // the final order deterministic.
-__global__ __launch_bounds__(256) void bin_scatter_kernel(int64_t n, const u2* __restrict__ rect, const uint32_t* __restrict__ tiles,
-                                                          const uint32_t* __restrict__ mask, const float* __restrict__ depth, int lists_x, int nb,
-                                                          const uint32_t* __restrict__ bin_total, const uint32_t* __restrict__ block_off,
-                                                          uint32_t* __restrict__ bin_start, uint32_t n_binned,
-                                                          uint64_t* __restrict__ bvals) {
-    __shared__ uint32_t cur[MAX_BINS], wsum[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const BlockPairs bp = load_block_pairs(n, rect, tiles, mask, depth);
-    // exclusive prefix of the bin totals: thread t owns a contiguous run of ceil(nb / 256) bins.  The first four of a thread's
-    // totals and block offsets are loaded up front (all of them up to 1024 bins = 4 M pixels): one round trip, not three.
-    const int per = (nb + 255) / 256, first = tid * per;
-    uint32_t bt[4], bo[4];
+// The scatter of a wave's large Gaussians, one after the other: the lanes take the rows of the rectangle, every row's span is cut at the
+// coarse-bin boundaries (a span of up to 33 lists crosses at most one: two rounds), each piece draws a run of slots from its bin's
+// cursor in LDS -- and then the PAIRS, not the rows, are dealt to the lanes (`owner`: which lane's piece pair k belongs to), so that a
+// store instruction writes up to 64 consecutive payloads instead of one 8-byte word into each of ~20 different runs.
+constexpr int BIG_ROUND_PAIRS = 64 * 34;             // 64 rows x the widest span a rectangle can have (radius <= 250 px: 33 lists)
+__device__ __forceinline__ void scatter_big_rows(const BigLane& bl, int lists_x, int lane, uint32_t* cur, uint8_t* owner, uint32_t n_binned,
+                                                 uint64_t* __restrict__ bvals) {
+    unsigned long long m = __ballot(bl.big);
+    while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+#define RL_F(x) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src))
+        const uint32_t rx = (uint32_t)__builtin_amdgcn_readlane((int)bl.rect.x, src), ry = (uint32_t)__builtin_amdgcn_readlane((int)bl.rect.y, src);
+        const float kk[4] = {RL_F(bl.k4.x), RL_F(bl.k4.y), RL_F(bl.k4.z), RL_F(bl.k4.w)};
+        const uint64_t pl = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(bl.payload >> 32), src) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)bl.payload, src);
+        const int x0 = rx & 0xFFFF, y0 = rx >> 16, x1 = ry & 0xFFFF, y1 = ry >> 16;
+        const BigSpanK bk = big_span_setup(RL_F(bl.uvexy.x), RL_F(bl.uvexy.y), RL_F(bl.uvexy.z), RL_F(bl.uvexy.w), kk, x0, x1);
+#undef RL_F
+        for (int yb = y0; yb <= y1; yb += 64) {                         // 64 rows per pass (one pass up to 512-pixel-high rectangles)
+            const int y = yb + lane;
+            RowSpan sp = RowSpan{1, 0};
+            if (y <= y1) sp = big_row_span(bk, y);
+            const bool has = sp.xb >= sp.xa;
+            const uint32_t l0 = has ? (uint32_t)(y * lists_x + sp.xa) : 0u, l1 = has ? (uint32_t)(y * lists_x + sp.xb) : 0u;
+            const uint32_t cut = ((l0 >> BIN_SHIFT) + 1u) << BIN_SHIFT;  // first list of the next bin
+            for (int round = 0; round < 2; ++round) {
+                // piece of this round: [a, a + c)
+                const uint32_t a = round == 0 ? l0 : cut;
+                const uint32_t c = !has ? 0u : (round == 0 ? min(l1 + 1u, cut) - l0 : (l1 >= cut ? l1 + 1u - cut : 0u));
+                if (!__any(c != 0u)) continue;
+                const uint32_t pos = c ? atomicAdd(&cur[a >> BIN_SHIFT], c) : 0u;
+                uint32_t incl = c;
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t up_ = (uint32_t)__shfl_up((int)incl, d);
+                    if (lane >= d) incl += up_;
+                }
+                const uint32_t pre = incl - c, total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                for (uint32_t j = 0; j < c; ++j) owner[pre + j] = (uint8_t)lane;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (uint32_t k0 = 0; k0 < total; k0 += 64) {                   // (uniform trip count: a shuffle reads nothing from a lane that
+                    const uint32_t k = k0 + (uint32_t)lane;                     //  has left the loop)
+                    const int o = k < total ? owner[k] : 0;
+                    const uint32_t j = k - (uint32_t)__shfl((int)pre, o);
+                    const uint32_t dst = (uint32_t)__shfl((int)pos, o) + j, l = (uint32_t)__shfl((int)a, o) + j;
+                    if (k < total && dst < n_binned) bvals[dst] = pl | ((uint64_t)(l & ((1u << BIN_SHIFT) - 1u)) << ID_BITS);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();                                // `owner` is rewritten by the next round
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+    }
+}
+
+// A bin's region of the bin-ordered array: [ pairs of the small Gaussians | pairs of the large ones ]; the small blocks place theirs
+// with the offsets bin_count_kernel drew (block_off), the big blocks (same split of the grid as there) count their range again,
+// draw ONE offset per touched bin from the bin's cursor (bin_total + 2 nb) and scatter.
+//
+// Exclusive prefix of the bin totals (small + large) for both kinds of block: thread t owns a contiguous run of ceil(nb / 256) bins and
+// calls own(b, start of bin b, total of bin b, k) for each of them (k = index inside the run; the first four totals are in bt[]).
+// The first four of a thread's totals are loaded up front (all of them up to 1024 bins = 4 M pixels): one round trip, not three.
+struct BinPrefix { int per, first; uint32_t bt[4], run; };
+__device__ __forceinline__ BinPrefix bin_prefix_load(const uint32_t* __restrict__ bin_total, int nb) {
+    BinPrefix p;
+    p.per = (nb + 255) / 256;
+    p.first = (int)threadIdx.x * p.per;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const bool in = k < per && first + k < nb;
-        bt[k] = in ? bin_total[first + k] : 0u;
-        bo[k] = in ? block_off[(int64_t)blockIdx.x * nb + first + k] : 0u;
+        const bool in = k < p.per && p.first + k < nb;
+        p.bt[k] = in ? bin_total[p.first + k] + bin_total[nb + p.first + k] : 0u;
     }
-    uint32_t run = bt[0] + bt[1] + bt[2] + bt[3];
-    for (int k = 4; k < per; ++k) run += first + k < nb ? bin_total[first + k] : 0u;
-    uint32_t incl = run;
+    p.run = p.bt[0] + p.bt[1] + p.bt[2] + p.bt[3];
+    for (int k = 4; k < p.per; ++k) p.run += p.first + k < nb ? bin_total[p.first + k] + bin_total[nb + p.first + k] : 0u;
+    return p;
+}
+// start of the thread's first bin (one workgroup barrier inside)
+__device__ __forceinline__ uint32_t bin_prefix_scan(const BinPrefix& p, uint32_t* wsum) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = p.run;
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t up_ = (uint32_t)__shfl_up((int)incl, d);
         if (lane >= d) incl += up_;
     }
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    uint32_t st = incl - run;
+    uint32_t st = incl - p.run;
     for (int k = 0; k < wave; ++k) st += wsum[k];
-    for (int k = 0; k < per; ++k) {
-        const int b = first + k;
+    return st;
+}
+
+__device__ __forceinline__ void bin_scatter_big(int64_t n, const u2* __restrict__ rect, const uint32_t* __restrict__ tiles,
+                                                          const float* __restrict__ depth, int lists_x, int nb, uint32_t* __restrict__ bin_total,
+                                                          uint32_t n_binned, uint64_t* __restrict__ bvals, const Rec64* __restrict__ rec,
+                                                          const uint32_t* __restrict__ big_flag, uint32_t small_blocks, uint32_t* cur, uint32_t* wsum,
+                                                          uint8_t* owner) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t ranges = (n + 255) / 256;
+    if (!any_big_range(big_flag, blockIdx.x - small_blocks, gridDim.x - small_blocks, ranges)) return;
+    for (int64_t range = blockIdx.x - small_blocks; range < ranges; range += gridDim.x - small_blocks) {
+        BigLane bl;
+        if (!load_big_lane(range * 256 + tid, n, rect, tiles, rec, depth, bl, big_flag)) continue;
+        const BinPrefix bpf = bin_prefix_load(bin_total, nb);
+        for (int b = tid; b < nb; b += 256) cur[b] = 0u;
+        __syncthreads();
+        for_each_big_row(bl.big, bl.rect, bl.uvexy, bl.k4, 0ull, lists_x, lane, [&](uint32_t l0, uint32_t cnt, uint64_t) {
+            for_bin_pieces(l0, cnt, [&](uint32_t b, uint32_t, uint32_t c) { atomicAdd(&cur[b], c); });      // this range's pairs per bin
+        });
+        uint32_t st = bin_prefix_scan(bpf, wsum);              // (its barrier also closes the counting)
+        for (int k = 0; k < bpf.per; ++k) {
+            const int b = bpf.first + k;
+            if (b < nb) {
+                // start of the bin + its small part + what this block draws from the large part's cursor (ONE returning atomic per
+                // touched bin and block)
+                const uint32_t mine = cur[b];
+                if (mine) cur[b] = st + bin_total[b] + atomicAdd(&bin_total[2 * nb + b], mine);
+                st += k < 4 ? bpf.bt[k & 3] : bin_total[b] + bin_total[nb + b];
+            }
+        }
+        __syncthreads();
+        scatter_big_rows(bl, lists_x, lane, cur, owner, n_binned, bvals);
+        __syncthreads();                                        // cur is cleared again by the next range
+    }
+}
+
+__global__ __launch_bounds__(256) void bin_scatter_kernel(int64_t n, const u2* __restrict__ rect, const uint32_t* __restrict__ tiles,
+                                                          const uint32_t* __restrict__ mask, const float* __restrict__ depth, int lists_x, int nb,
+                                                          uint32_t* __restrict__ bin_total, const uint32_t* __restrict__ block_off,
+                                                          uint32_t* __restrict__ bin_start, uint32_t n_binned,
+                                                          uint64_t* __restrict__ bvals, const Rec64* __restrict__ rec,
+                                                          const uint32_t* __restrict__ big_flag, uint32_t small_blocks) {
+    __shared__ uint32_t cur[MAX_BINS], wsum[4];
+    __shared__ uint8_t owner[4][BIG_ROUND_PAIRS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (blockIdx.x >= small_blocks) {            // ---- ranges of 256 Gaussians (grid-stride): the large ones of each range
+        bin_scatter_big(n, rect, tiles, depth, lists_x, nb, bin_total, n_binned, bvals, rec, big_flag, small_blocks, cur, wsum, owner[wave]);
+        return;
+    }
+    const BlockPairs bp = load_block_pairs(n, rect, tiles, mask, depth);
+    const BinPrefix bpf = bin_prefix_load(bin_total, nb);
+    uint32_t bo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bo[k] = (k < bpf.per && bpf.first + k < nb) ? block_off[(int64_t)blockIdx.x * nb + bpf.first + k] : 0u;
+    uint32_t st = bin_prefix_scan(bpf, wsum);
+    for (int k = 0; k < bpf.per; ++k) {
+        const int b = bpf.first + k;
         if (b < nb) {
-            const uint32_t c = k < 4 ? bt[k & 3] : bin_total[b];
+            const uint32_t c = k < 4 ? bpf.bt[k & 3] : bin_total[b] + bin_total[nb + b];
             cur[b] = st + (k < 4 ? bo[k & 3] : block_off[(int64_t)blockIdx.x * nb + b]);   // garbage for bins this block never touches: unused
             if (blockIdx.x == 0) {
                 bin_start[b] = st;
@@ -735,8 +960,8 @@ __device__ __forceinline__ uint32_t work_bucket(uint32_t w) {
     const uint32_t e = 31u - (uint32_t)__clz((int)w);
     return (e - 2u) * 8u + ((w >> (e - 3u)) & 7u);          // <= 239; 256 -> 48, 1024 -> 64, 4096 -> 80, 8192 -> 88
 }
-constexpr int SORT_CLASSES = 3;                               // list length >= 1024 | >= 256 | >= 1
-__device__ __forceinline__ uint32_t class_first_bucket(int c) { return c == 0 ? 64u : (c == 1 ? 48u : 1u); }
+constexpr int SORT_CLASSES = 4;                               // list length >= 4096 | >= 1024 | >= 256 | >= 1
+__device__ __forceinline__ uint32_t class_first_bucket(int c) { return c == 0 ? 80u : (c == 1 ? 64u : (c == 2 ? 48u : 1u)); }
 
 // Counting sort of the lists by work bucket, descending.  Same-address LDS atomics serialise and neighbouring lists
 // often share a bucket, so every bucket has 16 sub-counters selected by the lane (flat index = (255 - bucket) * 16 + sub:
@@ -1038,16 +1263,20 @@ __device__ __forceinline__ void sort_list(SortLds<T, E, LOG2B>& s, int tid, uint
 #undef PADC
 }
 
-// class 0 (lists of 1024 entries and more): one workgroup of 512 threads per list, 100 KB of LDS; grid-stride over the class's
-// lists -- the grid is sized for the chip, not for the worst-case number of lists (a workgroup of this class occupies a whole
-// CU even when it only finds out that it has nothing to do)
-template <int T, int E, int LOG2B>
+// The two classes of long lists, one workgroup per list, grid-stride over the class's lists (the grids are sized for the chip, not
+// for the worst-case number of lists):
+//   class 0 (4096 entries and more)  <1024, 8, 13>: 100 KB of LDS, one workgroup per CU; lists of 8192+ sort in global memory
+//   class 1 (1024 .. 4095)           <512, 8, 12>:   50 KB, three per CU.  (One class for everything from 1024 up kept a whole CU busy
+//                                    with every 1100-entry list: 178 us at config 5, 350 us with the footprints of a trained scene.)
+// (class 0 is only launched where lists of 4096 entries are plausible -- see gsplat_bin --; otherwise class 1's launch covers it
+//  (`with_class0`), sorting the odd list that long in global memory: exact, slow, rare)
+template <int T, int E, int LOG2B, int CLASS>
 __global__ __launch_bounds__(T) void list_sort_kernel(const uint32_t* __restrict__ order, const uint32_t* __restrict__ class_bounds,
                                                       const uint2* __restrict__ ranges, uint64_t* __restrict__ vals,
-                                                      uint32_t* __restrict__ sorted_ids) {
+                                                      uint32_t* __restrict__ sorted_ids, int with_class0) {
     __shared__ SortLds<T, E, LOG2B> s;
-    const uint32_t hi = class_bounds[0];
-    for (uint32_t b = blockIdx.x; b < hi; b += gridDim.x)
+    const uint32_t lo = (CLASS == 0 || with_class0) ? 0u : class_bounds[CLASS - 1], hi = class_bounds[CLASS];
+    for (uint32_t b = lo + blockIdx.x; b < hi; b += gridDim.x)
         sort_list<T, E, LOG2B, false, true>(s, threadIdx.x, ranges[order[b]], vals, sorted_ids);
 }
 
@@ -1063,11 +1292,11 @@ __global__ __launch_bounds__(256) void list_sort_small_kernel(const uint32_t* __
                                                               uint64_t* __restrict__ vals, uint32_t* __restrict__ sorted_ids) {
     __shared__ SortSmallLds s;
     if (blockIdx.x < mid_blocks) {
-        const uint32_t lo = class_bounds[0], hi = class_bounds[1];
+        const uint32_t lo = class_bounds[1], hi = class_bounds[2];
         for (uint32_t b = blockIdx.x; lo + b < hi; b += mid_blocks)
             sort_list<256, 4, 11, false, false>(s.mid, threadIdx.x, ranges[order[lo + b]], vals, sorted_ids);
     } else {
-        const uint32_t lo = class_bounds[1], hi = class_bounds[2];
+        const uint32_t lo = class_bounds[2], hi = class_bounds[3];
         const uint32_t wave = threadIdx.x >> 6, stride = (gridDim.x - mid_blocks) * 4u;
         for (uint32_t b = (blockIdx.x - mid_blocks) * 4u + wave; lo + b < hi; b += stride)
             sort_list<64, 4, 9, true, false>(s.small[wave], (int)(threadIdx.x & 63), ranges[order[lo + b]], vals, sorted_ids);
@@ -1697,7 +1926,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             const uint32_t mk = det.mask[id], nt = det.tiles[id];
             const int x0 = (int)(rc.x & 0xFFFFu), y0 = (int)(rc.x >> 16), x1 = (int)(rc.y & 0xFFFFu);
             const uint32_t bit = (uint32_t)((hy - y0) * (x1 - x0 + 1) + (tx - x0));          // row-major, like for_each_list
-            const uint32_t ord = nt > 32u ? bit : (uint32_t)__popc(mk & ((1u << (bit & 31u)) - 1u));
+            uint32_t ord;
+            if (rect_is_big(rc)) {               // a large Gaussian: its lists are row spans (for_each_big_row): lists in the rows above + offset in this row
+                const Rec64* r = rec + id;
+                const f4 q0 = r->r0, q1 = r->r1, q3 = r->pad;
+                const float kk[4] = {q3.x, q3.y, q3.z, q3.w};
+                const BigSpanK bk = big_span_setup(q0.x, q0.y, q1.z, q1.w, kk, x0, x1);
+                ord = 0u;
+                for (int y = y0; y < hy; ++y) {
+                    const RowSpan sp = big_row_span(bk, y);
+                    if (sp.xb >= sp.xa) ord += (uint32_t)(sp.xb - sp.xa + 1);
+                }
+                ord += (uint32_t)(tx - big_row_span(bk, hy).xa);
+            } else {
+                ord = (uint32_t)__popc(mk & ((1u << (bit & 31u)) - 1u));
+            }
+            (void)nt;
             sb.eslot[lane] = det.pair_base[id] + ord;
         }
         __syncthreads();
@@ -2052,6 +2296,12 @@ __global__ __launch_bounds__(64) void evaluate_sh_backward_kernel(int64_t n, con
 }
 
 inline unsigned blocks256(int64_t n) { return (unsigned)((n + 255) / 256); }
+// workgroups of the binning kernels that look for LARGE Gaussians (ranges of 256, grid-stride): enough to fill the chip when every
+// Gaussian is large, few enough to cost a scene without any (config 3: 3906 ranges) almost nothing
+#ifndef GSPLAT_BIG_BLOCKS_MAX
+#define GSPLAT_BIG_BLOCKS_MAX 512u
+#endif
+inline unsigned big_bin_blocks(int64_t n) { return std::min(blocks256(n), GSPLAT_BIG_BLOCKS_MAX); }
 inline unsigned blocks64(int64_t n) { return (unsigned)((n + 63) / 64); }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -2137,9 +2387,9 @@ int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_vie
 #define LAUNCH_PROJECT(F, C, J, KJ)                                                                                                     \
     do {                                                                                                                                \
         if (late) hipLaunchKernelGGL((project_kernel<F, C, J, false>), grid, block, 0, st, *g, c2w, ps.cam, vk, out, cb, ps.counts, cm,  \
-                                     ps.bin_total, (int)nb, KJ);                                                                        \
+                                     ps.bin_total, (int)nb, KJ, ps.big_flag);                                                           \
         else hipLaunchKernelGGL((project_kernel<F, C, J, true>), grid, block, 0, st, *g, c2w, ps.cam, vk, out, cb, ps.counts, cm,        \
-                                ps.bin_total, (int)nb, KJ);                                                                             \
+                                ps.bin_total, (int)nb, KJ, ps.big_flag);                                                                \
     } while (0)
         if (!fused) LAUNCH_PROJECT(false, true, false, nullptr);
         else if (colour_inside && jac) LAUNCH_PROJECT(true, true, true, ps.kj);
@@ -2150,14 +2400,14 @@ int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_vie
         if (counts_host && !mapped && !late) HIP_TRY(hipMemcpyAsync(counts_host, ps.counts, sizeof(gsplat_counts), hipMemcpyDeviceToHost, st));
     } else {                        // no kernel runs: the counters are zero by definition
         HIP_TRY(hipMemsetAsync(ps.counts, 0, sizeof(DevCounts), st));
-        HIP_TRY(hipMemsetAsync(ps.bin_total, 0, nb * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(ps.bin_total, 0, 3 * nb * sizeof(uint32_t), st));
         if (counts_host) HIP_TRY(hipMemsetAsync(counts_host, 0, sizeof(gsplat_counts), st));
     }
     if (counts_event && !late) HIP_TRY(hipEventRecord((hipEvent_t)counts_event, st));
     if (n > 0) {                    // these need no pair buffer: queued behind the event, they run while a waiting host sizes the buffers
-        hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)n_bin_blocks(n)), dim3(256), 0, st, n, ps.rect, ps.tiles, ps.mask, vk.lists_x, (int)nb,
+        hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)(n_bin_blocks(n) + big_bin_blocks(n))), dim3(256), 0, st, n, ps.rect, ps.tiles, ps.mask, vk.lists_x, (int)nb,
                            ps.bin_total, ps.block_off, ps.list_count, ps.ranges, (int)nl, late ? (CounterBlock*)scratch : nullptr, ps.counts,
-                           late && mapped ? (DevCounts*)counts_host : nullptr);
+                           late && mapped ? (DevCounts*)counts_host : nullptr, ps.rec, ps.big_flag, (uint32_t)n_bin_blocks(n));
         LAUNCH_CHECK("bin_count_kernel");
         if (late) {                 // the counters exist only now
             if (counts_host && !mapped) HIP_TRY(hipMemcpyAsync(counts_host, ps.counts, sizeof(gsplat_counts), hipMemcpyDeviceToHost, st));
@@ -2192,8 +2442,9 @@ int gsplat_bin(int64_t n, int64_t pair_capacity, const gsplat_view* v, const voi
     BinScratch sc = carve_bin_scratch(scratch, n_binned, nb);
     if (!scratch || sc.bytes > scratch_bytes) return fail(GSPLAT_ERR_WORKSPACE, "bin scratch too small");
     uint32_t* sorted_ids = (uint32_t*)bin_state;
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3((unsigned)n_bin_blocks(n)), dim3(256), 0, st, n, ps.rect, ps.tiles, ps.mask, ps.depth, vk.lists_x,
-                       (int)nb, ps.bin_total, ps.block_off, ps.bin_start, (uint32_t)n_binned, sc.bvals);
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3((unsigned)(n_bin_blocks(n) + big_bin_blocks(n))), dim3(256), 0, st, n, ps.rect, ps.tiles, ps.mask, ps.depth, vk.lists_x,
+                       (int)nb, ps.bin_total, ps.block_off, ps.bin_start, (uint32_t)n_binned, sc.bvals, ps.rec, ps.big_flag,
+                       (uint32_t)n_bin_blocks(n));
     LAUNCH_CHECK("bin_scatter_kernel");
     hipLaunchKernelGGL(split_count_kernel, dim3((unsigned)n_chunks(n_binned)), dim3(256), 0, st, (int)nb, ps.bin_start, sc.bvals,
                        (uint32_t)n_binned, ps.counts, ps.list_count, sc.seg_off);
@@ -2204,10 +2455,19 @@ int gsplat_bin(int64_t n, int64_t pair_capacity, const gsplat_view* v, const voi
     // F9 + F12: per-list sort by (depth, index); one launch per size class, grids bounded by what the class can hold
     uint64_t* vals = sc.vals;
     const auto cap = [&](int64_t min_len) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(nl, n_binned / min_len)); };
-    if (n_binned >= 1024) {       // lists of 1024+ entries: 100 KB of LDS per workgroup; 8192+ fall back to global memory inside
-        hipLaunchKernelGGL((list_sort_kernel<1024, 8, 13>), dim3(std::min(cap(1024), 256u)), dim3(1024), 0, st, ps.order, ps.class_bounds, ps.ranges,
-                           vals, sorted_ids);
+    // lists of 4096+ entries: 100 KB of LDS per workgroup (8192+ fall back to global memory inside).  An empty launch of that kernel
+    // still costs ~4 us, so it is made only where the AVERAGE list has 256 entries (lists 16x the average are the far tail: the longest
+    // list of config 3 is 12x its average of 200); elsewhere the launch below takes such a list too.
+    const bool class0 = n_binned >= 4096 && n_binned >= 256 * nl;
+    if (class0) {
+        hipLaunchKernelGGL((list_sort_kernel<1024, 8, 13, 0>), dim3(std::min(cap(4096), 256u)), dim3(1024), 0, st, ps.order, ps.class_bounds, ps.ranges,
+                           vals, sorted_ids, 0);
         LAUNCH_CHECK("list_sort_kernel<8192>");
+    }
+    if (n_binned >= 1024) {       // lists of 1024 .. 4095 entries: 50 KB per workgroup
+        hipLaunchKernelGGL((list_sort_kernel<512, 8, 12, 1>), dim3(std::min(cap(1024), 768u)), dim3(512), 0, st, ps.order, ps.class_bounds, ps.ranges,
+                           vals, sorted_ids, class0 ? 0 : 1);
+        LAUNCH_CHECK("list_sort_kernel<4096>");
     }
     {
         const unsigned mid_blocks = n_binned >= 256 ? std::min(cap(256), 4096u) : 0u;

@@ -35,6 +35,20 @@ void hm_project_backward(const gsplat_gaussians* g, const float* c2w, const gspl
     }
 }
 
+// the row spans of a large Gaussian's rectangle (gs_math.h big_row_span), as the binning kernels enumerate them: xa[r], xb[r] for the
+// rows by0 .. by1 of the rectangle (rect_lo = bx0 | by0 << 16, rect_hi = bx1 | by1 << 16); empty rows have xa > xb
+void hm_row_spans(const float* rec16, uint32_t rect_lo, uint32_t rect_hi, const gsplat_view* v, int32_t* xa, int32_t* xb) {
+    const ViewK vk = make_viewk(*v);
+    const int bx0 = rect_lo & 0xFFFF, by0 = rect_lo >> 16, bx1 = rect_hi & 0xFFFF, by1 = rect_hi >> 16;
+    float k4[4];
+    big_span_constants(rec16[2], rec16[3], rec16[4], rec16[6], vk.chi_pad, k4);
+    const BigSpanK bk = big_span_setup(rec16[0], rec16[1], rec16[6], rec16[7], k4, bx0, bx1);
+    for (int y = by0; y <= by1; ++y) {
+        const RowSpan sp = big_row_span(bk, y);
+        xa[y - by0] = sp.xa; xb[y - by0] = sp.xb;
+    }
+}
+
 void hm_build_sigma(int64_t n, const float* scale_raw, const float* q_raw, float* sigma) {
     for (int64_t i = 0; i < n; ++i) build_sigma_one(i, scale_raw, q_raw, sigma);
 }

@@ -50,7 +50,10 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E p
 
 # config id -> (N, H, W, fx, mu_s)      SURVEY.md §8(d)
 CONFIGS = {1: (10_000, 256, 256, 300.0, -3.0), 2: (100_000, 800, 800, 800.0, -4.5), 3: (1_000_000, 1080, 1920, 1100.0, -5.0),
-           4: (3_000_000, 1080, 1920, 1100.0, -5.4), 5: (10_000_000, 2160, 3840, 2200.0, -5.8)}
+           4: (3_000_000, 1080, 1920, 1100.0, -5.4), 5: (10_000_000, 2160, 3840, 2200.0, -5.8),
+           # 6 is not a BASELINE.json config: config 2's scene with the footprints of a TRAINED scene (log-scale mean -2.0 instead of
+           # -4.5: radii of ~75 px instead of ~6; every Gaussian covers hundreds of lists and the lists saturate early)
+           6: (100_000, 800, 800, 800.0, -2.0)}
 NAMES = ("pos", "f_dc", "f_rest", "opacity_raw", "scale_raw", "q_raw")
 
 
@@ -111,6 +114,32 @@ def pmc_traffic(kernel, config=3):
             v = max(hits, key=lambda x: x.get("hbm_bytes_per_launch", 0.0)) if hits else None
         return float(v["hbm_bytes_per_launch"]) if v else None
     except (OSError, ValueError, KeyError, TypeError):
+        return None
+
+
+def valu_figures(kernel, config=3):
+    """SURVEY.md 8(d)'s second roofline figure for the raster kernels: VALU work, from COMMITTED profiles of this scene --
+    profiles/valu_config<N>.json (tools/valu_summary.py over `rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE`, tools/sq_counters.sh)
+    and profiles/r03_raster_sim_config<N>.json (tools/raster_sim.py: the loop iterations and the (pixel, Gaussian) evaluations that land
+    inside an ellipse, counted by replaying the kernels' queue construction on the CPU).  None when the files are absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", f"valu_config{config}.json")) as f:
+            v = json.load(f)
+        k = next((x for name, x in v.items() if name.split("<")[0] == kernel and isinstance(x, dict)), None)
+        if k is None:
+            return None
+        out = {"kernel": kernel, "valu_wave_instructions_per_launch": k["insts_valu"], "valu_busy": k["busy"], "source": v.get("_source")}
+        try:
+            with open(os.path.join(ROOT, "profiles", f"r03_raster_sim_config{config}.json")) as f:
+                sim = json.load(f)
+            out.update({"loop_iterations_per_launch": sim["iterations"], "useful_lane_fraction": sim["useful_lane_fraction"],
+                        "queue_imbalance": sim["queue_imbalance"],
+                        "valu_wave_instructions_per_iteration": k["insts_valu"] / sim["iterations"],
+                        "valu_lane_instructions_per_composited_pixel_gaussian": k["insts_valu"] * 64 / sim["inside_evaluations"]})
+        except (OSError, ValueError, KeyError):
+            pass
+        return out
+    except (OSError, ValueError, KeyError, StopIteration):
         return None
 
 
@@ -260,6 +289,8 @@ def main():
     ap.add_argument("--launch-check", action="store_true", help="only check the rank launch + process group (no GPU needed)")
     ap.add_argument("--deterministic", action="store_true", help="bitwise reproducible gradients (ops.set_deterministic): rows per "
                     "(list, Gaussian) pair stored and added in a fixed order instead of float atomics")
+    ap.add_argument("--views-per-rank", type=int, default=1, help="camera views every rank renders per step (one gradient exchange per step: "
+                    "the exchange amortises over the views; BASELINE.json's config 4 is 1 view per GPU)")
     ap.add_argument("--separate-calls", action="store_true", help="ablation: a deferred frame goes through the separate library calls "
                     "(gsplat_project, gsplat_bin, ...) instead of the two composite entries")
     ap.add_argument("--wait-counts", action="store_true", help="every forward pass waits for its pair count (exact buffers) instead of "
@@ -315,7 +346,9 @@ def main():
     need_grad = not args.forward_only
     params = {k: params_cpu[k].to(dev).requires_grad_(need_grad) for k in NAMES}
     del params_cpu
-    c2w = orbit_c2w(rank % 8).to(dev)                       # data parallel by camera view: rank r renders view r
+    vpr = max(1, args.views_per_rank)
+    c2ws = [orbit_c2w((rank * vpr + i) % 8).to(dev) for i in range(vpr)]      # data parallel by camera view: rank r renders views r V .. r V + V - 1
+    c2w = c2ws[0]
     gimg = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(1)).to(dev)
     cam_args = (H, W, cam["fx"], cam["fy"], cam["cx"], cam["cy"])
 
@@ -332,10 +365,12 @@ def main():
         if need_grad:
             for p in params.values():
                 p.grad = None
-            gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args).backward(gimg)
+            for c in c2ws:                                   # (gradients of the rank's views accumulate in .grad)
+                gs.render_gaussians(*[params[k] for k in NAMES], c, *cam_args).backward(gimg)
         else:
             with torch.no_grad():
-                gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args)
+                for c in c2ws:
+                    gs.render_gaussians(*[params[k] for k in NAMES], c, *cam_args)
 
     def local_step():
         checked(render_pass)
@@ -348,8 +383,9 @@ def main():
             def factored_pass():
                 for p in params.values():
                     p.grad = None
-                with dp.FactoredExchange(params, world_views=world) as ex:
-                    gs.render_gaussians(*[params[k] for k in NAMES], c2w, *cam_args).backward(gimg)
+                with dp.FactoredExchange(params, world_views=world * vpr) as ex:
+                    for c in c2ws:                           # view k's logit gradients are gathered while view k + 1 renders
+                        gs.render_gaussians(*[params[k] for k in NAMES], c, *cam_args).backward(gimg)
                 return ex
             # (a repeat would re-issue this rank's collectives: it cannot happen in the timed region -- every rank renders the same view
             # in every step, and the warm-up steps left it the capacity of that view; training.Trainer.step, where views change, agrees
@@ -363,7 +399,7 @@ def main():
             grads = [params[k].grad for k in NAMES]
             info[mode] = "all-reduce of all six gradient tensors (236 B per Gaussian): " + \
                          ("one flat buffer, single collective" if dp._common_base(grads) is not None else "2 buckets")
-            dp.allreduce_gradients(grads, world_views=world)
+            dp.allreduce_gradients(grads, world_views=world * vpr)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -436,10 +472,10 @@ def main():
 
         def collectives():
             if args.exchange == "factored":
-                w1 = dist.all_gather_into_tensor(gathered, logit, async_op=True)
-                w2 = dist.all_reduce(small, async_op=True)
-                w1.wait()
-                w2.wait()
+                ws = [dist.all_gather_into_tensor(gathered, logit, async_op=True) for _ in range(vpr)]
+                ws.append(dist.all_reduce(small, async_op=True))
+                for w_ in ws:
+                    w_.wait()
             else:
                 dist.all_reduce(full)
         alone_ms = None
@@ -461,8 +497,8 @@ def main():
             "other_mode": {"mode": alt, "what": info.get(alt), "step_ms": alt_ms, "error": alt_err},
             "step_ms": ms, "compute_ms": compute_ms, "exchange_ms": ms - compute_ms, "exchange_alone_ms": alone_ms,
             "allreduce_bytes_per_step": (44 if args.exchange == "factored" else 236) * N,
-            "allgather_bytes_per_rank_per_step": 12 * N if args.exchange == "factored" else 0,
-            "allgather_bytes_received_per_step": 12 * N * world if args.exchange == "factored" else 0,
+            "allgather_bytes_per_rank_per_step": 12 * N * vpr if args.exchange == "factored" else 0,
+            "allgather_bytes_received_per_step": 12 * N * world * vpr if args.exchange == "factored" else 0,
             "note": "exchange_ms = step - compute: the part of the exchange the step does not hide; the SH rebuild "
                     "(gsplat_sh_accumulate) counts as exchange"}
     if world == 1 and rank == 0 and not args.no_extras and args.config == 3 and need_grad:
@@ -471,7 +507,7 @@ def main():
     if rank == 0:
         _, V, P = stats
         HW = H * W
-        value = world * HW * args.steps / elapsed / 1e6
+        value = world * vpr * HW * args.steps / elapsed / 1e6
         stage = dict(cal_stage)
         stage.update(timer.totals_ms())              # the dominant call: measured live inside the timed region
         per_stage = {k: {"launches": n, "avg_ms": t / n, "alg_bytes": algorithmic_bytes(k, N, V, P, HW),
@@ -480,7 +516,7 @@ def main():
         ach = per_stage[dom]["gbs"]
         fwd_b = 16 * N + 268 * V + 52 * P + 12 * HW
         bwd_b = 236 * N + 272 * V + 80 * P + 20 * HW
-        alg_total = fwd_b + (bwd_b if need_grad else 0)
+        alg_total = (fwd_b + (bwd_b if need_grad else 0)) * vpr
         out = {
             "metric": "rendered Mpix/s (fwd+bwd), 1M Gaussians @1080p SH3" if need_grad and args.config == 3 else
                       f"rendered Mpix/s ({'fwd+bwd' if need_grad else 'forward only'}), config {args.config}",
@@ -488,7 +524,7 @@ def main():
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"SURVEY §8d config {args.config}: {N} Gaussians, {W}x{H}, SH degree 3, "
-                                   f"{'forward+backward' if need_grad else 'forward only'}, one camera view per GPU per step"
+                                   f"{'forward+backward' if need_grad else 'forward only'}, {vpr if vpr > 1 else 'one'} camera view{'s' if vpr > 1 else ''} per GPU per step"
                                    + ((", gradient exchange over " + ("RCCL" if args.backend == "nccl" else args.backend + " (rehearsal)"))
                                       if world > 1 and need_grad else ""),
                        "N": N, "V": V, "P": P, "P_binned": p_binned,
@@ -496,12 +532,13 @@ def main():
                        "parallelism": f"dp{world} by camera view", "allreduce": info.get(args.exchange),
                        "counts": "waited for in every forward pass" if args.wait_counts else
                                  "not waited for: buffers from earlier frames, checks once per step (ops.deferred_checks, as Trainer.step)"},
-            "fps": world * args.steps / elapsed,
+            "fps": world * vpr * args.steps / elapsed, "views_per_rank": vpr,
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(KERNEL_OF_STAGE[dom], args.config), "kernel": KERNEL_OF_STAGE[dom],
                          "avg_launch_ms": per_stage[dom]["avg_ms"], "alg_bytes_per_launch": per_stage[dom]["alg_bytes"],
                          "note": "the raster kernels are VALU-bound, not HBM-bound (DESIGN.md section 6): the HBM fraction of this "
                                  "kernel is small by construction; pipeline_roofline prices the whole step"},
+            "valu": valu_figures(KERNEL_OF_STAGE[dom], args.config),
             "pipeline_roofline": {"alg_bytes_per_step": alg_total, "achieved": alg_total / (ms * 1e-3) / 1e9,
                                   "frac": alg_total / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s"},
             "stages": per_stage,
@@ -580,6 +617,40 @@ def single_gpu_extras(gs, ops, params, cam, cam_args, dev, fence):
         del tr4, model4, views4
     except Exception as e:
         out["config4"] = {"error": f"{type(e).__name__}: {e}"}
+    # -- footprints of a trained scene (config 6 above: config 2's scene at log-scale mean -2.0): where the front end, not the rasterizer, is the bound
+    try:
+        p6_cpu, cam6 = synthetic_scene(6)
+        p6 = {k: p6_cpu[k].to(dev).requires_grad_(True) for k in NAMES}
+        H6, W6 = cam6["H"], cam6["W"]
+        g6 = torch.rand(H6, W6, 3, generator=torch.Generator().manual_seed(1)).to(dev)
+        a6 = (H6, W6, cam6["fx"], cam6["fy"], cam6["cx"], cam6["cy"])
+        eye6 = torch.eye(4, device=dev)
+
+        def pass6():
+            for p in p6.values():
+                p.grad = None
+            gs.render_gaussians(*[p6[k] for k in NAMES], eye6, *a6).backward(g6)
+
+        def step6():
+            ops.run_deferred(pass6)
+        for _ in range(3):
+            step6()
+        _, V6, P6 = gs.render_stats()
+        pb6 = ops.binned_pairs()
+        cal = ops.StageTimer()
+        ops.set_stage_timer(cal)
+        for _ in range(3):
+            step6()
+        fence()
+        ops.set_stage_timer(None)
+        st6 = {k: t / n for k, (n, t) in cal.totals_ms().items()}
+        ms6 = timed(step6, 10, fence)
+        out["big_footprint"] = {"workload": "config 2's scene (100 k Gaussians, 800x800, SH 3) with log-scale mean -2.0: footprints of ~75 px, forward + backward",
+                                "ms_per_step": ms6, "mpix_per_s": H6 * W6 / (ms6 * 1e-3) / 1e6, "V": V6, "P": P6, "P_binned": pb6, "stage_ms": st6,
+                                "front_end_ms": st6.get("project", 0.0) + st6.get("bin", 0.0)}
+        del p6, g6
+    except Exception as e:
+        out["big_footprint"] = {"error": f"{type(e).__name__}: {e}"}
     # -- config 5 (10 M Gaussians, 3840 x 2160, forward + backward)
     for p in params.values():
         p.grad = None

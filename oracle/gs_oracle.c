@@ -217,6 +217,8 @@ int ora_render(int64_t n, const double* pos, const double* f_dc, const double* f
             for (int py = tyi * T; py < (tyi + 1) * T && py < H; ++py)
                 for (int px = txi * T; px < (txi + 1) * T && px < W; ++px) {
                     double Tr = 1.0, C[3] = {0, 0, 0};
+                    int64_t used = cnt;        /* entries up to the one that kills the pixel (T <= 5e-5): every later one has w = 0 and, the
+                                                  suffix sum behind it being 0, d alpha = 0 -- skipping them changes no bit of any result */
                     for (int64_t j = 0; j < cnt; ++j) {
                         const ora_rec* r = rec + keys[s0 + j].k;
                         const double du = px - r->u, dv = py - r->v;
@@ -229,6 +231,7 @@ int ora_render(int64_t n, const double* pos, const double* f_dc, const double* f
                         const double w = (Tr > 5e-5) ? a * Tr : 0.0;
                         C[0] += w * r->rgb[0]; C[1] += w * r->rgb[1]; C[2] += w * r->rgb[2];
                         Tr *= (1.0 - a);
+                        if (!(Tr > 5e-5)) { used = j + 1; break; }
                     }
                     double* o = image + ((int64_t)py * W + px) * 3;
                     for (int c = 0; c < 3; ++c) o[c] = clampd(C[c], 0.0, 1.0);
@@ -236,7 +239,7 @@ int ora_render(int64_t n, const double* pos, const double* f_dc, const double* f
                     double G[3];
                     for (int c = 0; c < 3; ++c) G[c] = (C[c] >= 0.0 && C[c] <= 1.0) ? grad_image[((int64_t)py * W + px) * 3 + c] : 0.0;
                     double suffix = 0.0;                               /* sum over k > i of w_k (c_k . G) */
-                    for (int64_t j = cnt - 1; j >= 0; --j) {
+                    for (int64_t j = used - 1; j >= 0; --j) {
                         ora_rec* r = rec + keys[s0 + j].k;
                         const int alive = Tt[j] > 5e-5;
                         const double sdot = r->rgb[0] * G[0] + r->rgb[1] * G[1] + r->rgb[2] * G[2];

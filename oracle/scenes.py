@@ -19,6 +19,7 @@ CONFIGS = {
     3: (1_000_000, 1080, 1920, 1100.0, -5.0),
     4: (3_000_000, 1080, 1920, 1100.0, -5.4),
     5: (10_000_000, 2160, 3840, 2200.0, -5.8),
+    6: (100_000, 800, 800, 800.0, -2.0),       # not a BASELINE.json config: config 2 with the footprints of a trained scene (bench.py)
 }
 
 

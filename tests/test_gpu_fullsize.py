@@ -200,8 +200,9 @@ def test_full_frame_parity_vs_c_oracle(gs, cfg, counts, cal3):
     assert got[0] == counts[0] and abs(got[1] - counts[1]) <= slack, (got, counts, slack)
     (img * torch.tensor(w, device=DEV)).sum().backward()
     st, ref, g, (V, P) = c_oracle.render(s, *cam, grad_image=w.astype(np.float64))
-    # the float64 oracle differs from the reference's own fp32 counts in the same knife-edge radii
-    assert st == 0 and V == counts[0] and abs(P - counts[1]) <= slack
+    # the float64 oracle differs from the reference's own fp32 counts in the same kind of knife-edge radii: LAPACK's fp32 eigenvalues
+    # are off by more ulps than the kernel's closed form (config 3: 6 pairs, tools/ref_pairs_diff.py), so the band is wider here
+    assert st == 0 and V == counts[0] and abs(P - counts[1]) <= _knife_edge_pairs(cfg, ulps=64.0)[0]
     if cfg == 2:
         img32, g32 = _oracle_run(s, torch.eye(4), cam, w, torch.float32)
         cal_img, cal_g = util.image_errors(img32, ref), {k: util.grad_errors(g32[k], g[k]) for k in NAMES}
@@ -253,3 +254,30 @@ def test_wide_image_with_more_than_16384_lists(gs):
     util.check_image(img.detach().cpu().numpy(), ref, cal=img32)
     for k in NAMES:
         util.check_grad(p[k].grad.cpu().numpy(), gref[k], k, cal=g32[k])
+
+
+def test_big_footprints_full_frame_vs_c_oracle(gs):
+    """Config 2's scene with the footprints of a TRAINED scene (bench.py config 6: log-scale mean -2.0, radii of ~75 px): every
+    Gaussian covers hundreds of lists (rectangles far beyond the 32-list masks), the reference's P is 9.5 M for 100 k Gaussians,
+    every list saturates after a few hundred of its thousands of entries.  Full frame, forward + backward, against the plain-C
+    double-precision oracle; bounds calibrated by the float32 oracle on an 800 x 32 window of the same scene."""
+    from oracle import c_oracle
+    s, p, cam = _scene(6, grad=True)
+    H, W, fx, fy, cx, cy = cam
+    w = np.random.default_rng(1).uniform(0, 1, (H, W, 3)).astype(np.float32)
+    img = gs.render_gaussians(*[p[k] for k in NAMES], torch.eye(4, device=DEV), *cam)
+    (img * torch.tensor(w, device=DEV)).sum().backward()
+    st, ref, g, (V, P) = c_oracle.render(s, *cam, grad_image=w.astype(np.float64))
+    got = gs.render_stats(img)[1:]
+    slack = _knife_edge_pairs(6)[0]
+    print(f"config 6: V {got[0]} P {got[1]} (float64 oracle {V}, {P}; knife-edge slack {slack} pairs), binned pairs {gs.ops.binned_pairs()}")
+    assert st == 0 and got[0] == V and abs(got[1] - P) <= slack
+    h, y0 = 32, 384
+    ww = torch.tensor(w[y0:y0 + h])
+    win = (h, W, fx, fy, cx, cy - y0)
+    img64, g64 = _oracle_run(s, torch.eye(4), win, ww, torch.float64)
+    img32, g32 = _oracle_run(s, torch.eye(4), win, ww, torch.float32)
+    cal_img, cal_g = util.image_errors(img32, img64), {k: util.grad_errors(g32[k], g64[k]) for k in NAMES}
+    util.check_image(img.detach().cpu().numpy(), ref, cal=cal_img, what="config 6 image")
+    for k in NAMES:
+        util.check_grad(p[k].grad.cpu().numpy(), g[k], k, cal=cal_g[k])

@@ -175,11 +175,12 @@ def test_seeded_scene_vs_cpu_oracle(gs, n, hw, fx, mu):
         util.check_grad(p[k].grad.cpu().numpy(), p64[k].grad.numpy(), k, cal=g32[k])
 
 
-@pytest.mark.parametrize("n,longest", [(6000, 4096), (11000, 8192)])
-def test_long_lists_take_the_large_sort_paths(gs, n, longest):
+@pytest.mark.parametrize("n,longest,hw", [(6000, 4096, (32, 48)), (11000, 8192, (32, 48)), (6000, 4096, (512, 640))])
+def test_long_lists_take_the_large_sort_paths(gs, n, longest, hw):
     """Thousands of Gaussians on the same pixels: lists of 4096-8191 entries use the largest LDS sort class, longer ones are
-    sorted in global memory."""
-    H, W, f = 32, 48, 40.0
+    sorted in global memory.  Third case: the same hot spot in a large, otherwise empty image -- the average list is short, the class of
+    4096+ entries gets no launch of its own (gsplat_bin) and the launch of the 1024 .. 4095 class sorts the one long list in global memory."""
+    (H, W), f = hw, 40.0
     g = torch.Generator().manual_seed(11)
     z = torch.rand(n, generator=g, dtype=torch.float64) * 4 + 2          # distinct depths
     zs, order = torch.sort(z)

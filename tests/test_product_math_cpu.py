@@ -107,7 +107,18 @@ def test_forward_records_vs_reference_intermediates(hm, name):
     bm = rec[6][ids]
     area = (br[:, 2] - br[:, 0] + 1) * (br[:, 3] - br[:, 1] + 1)
     small = has & (area <= 32)
-    assert np.all(bt[has & ~small] == area[has & ~small]) and np.all(bm[has & ~small] == 0xFFFFFFFF)
+    # large rectangles: no mask; their lists are the row spans of big_row_span, and tiles[] counts exactly those
+    assert np.all(bm[has & ~small] == 0xFFFFFFFF) and np.all(bt[has & ~small] <= area[has & ~small])
+    view = abi.make_view(*util.cam_args(d), **d["kwargs"])
+    spans = {}
+    for k in np.nonzero(has & ~small)[0]:
+        h = int(br[k, 3] - br[k, 1] + 1)
+        xa, xb = np.zeros(h, np.int32), np.zeros(h, np.int32)
+        r16 = np.ascontiguousarray(np.concatenate([rec[0][ids[k]], rec[1][ids[k]]]), np.float32)
+        hm.hm_row_spans(_ptr(r16), C.c_uint32(int(bl[k])), C.c_uint32(int(bh[k])), C.byref(view), _ptr(xa), _ptr(xb))
+        assert int(np.maximum(xb - xa + 1, 0).sum()) == int(bt[k]), k
+        assert np.all((xa >= br[k, 0]) | (xa > xb)) and np.all(xb <= br[k, 2])
+        spans[int(k)] = (xa, xb)
     assert np.all(bt[small] == [bin(int(x)).count("1") for x in bm[small]])
     assert np.all(bm[small] >> area[small].astype(np.uint32) == 0)
     T = int(d["kwargs"].get("T", 16))           # the reference's tile size: its rectangle is in T x T tiles, the lists stay 16 x 8 pixels
@@ -115,7 +126,7 @@ def test_forward_records_vs_reference_intermediates(hm, name):
                   (br[has, 1] >= rect[has, 1] * T // 8) & (br[has, 3] <= (rect[has, 3] * T + T - 1) // 8))
     H, W = d["H"], d["W"]
     ys, xs = np.mgrid[0:H, 0:W]
-    for k in range(0, len(ids), max(1, len(ids) // 200)):
+    for k in sorted(set(range(0, len(ids), max(1, len(ids) // 200))) | set(np.nonzero(has & ~small)[0][:300].tolist())):
         du, dv = xs - float(d["im_u"][k]), ys - float(d["im_v"][k])
         q = con[k, 0, 0] * du * du + 2 * con[k, 0, 1] * du * dv + con[k, 1, 1] * dv * dv
         inside = q <= chi * (1 - 1e-6)
@@ -129,6 +140,10 @@ def test_forward_records_vs_reference_intermediates(hm, name):
         if area[k] <= 32:              # every list that holds such a pixel has its mask bit set
             bit = (ly - br[k, 1]) * (br[k, 2] - br[k, 0] + 1) + (lx - br[k, 0])
             assert np.all((int(bm[k]) >> bit) & 1), k
+        else:                          # ... or lies inside its row's span
+            xa, xb = spans[int(k)]
+            row = ly - br[k, 1]
+            assert np.all((lx >= xa[row]) & (lx <= xb[row])), k
 
 
 def _oracle_stage_grads(d, fused=True, color=None, sigma=None, seed=0):
@@ -262,3 +277,53 @@ def test_rotation_gradient_of_near_isotropic_gaussians_is_cancellation_free(hm):
     gs, gq = np.zeros_like(sr), np.zeros_like(qr)
     hm.hm_build_sigma_backward(C.c_int64(n), _ptr(sr), _ptr(qr), _ptr(w), _ptr(gs), _ptr(gq))
     assert np.linalg.norm(gq - b.grad.numpy()) / np.linalg.norm(b.grad.numpy()) <= 1e-4
+
+
+def test_row_spans_of_large_gaussians_cover_every_pixel_inside_the_ellipse(hm):
+    """gs_math.h big_row_span against brute force on random large ellipses (blobs and thin rotated needles, centres on and off the
+    grid): every list of every row that holds a pixel centre with q <= chi lies inside the row's span, and the spans are tight (a
+    span never reaches more than one list beyond the lists the padded ellipse touches)."""
+    rng = np.random.default_rng(4)
+    H, W = 400, 640
+    view = abi.make_view(H, W, 100.0, 100.0, W / 2, H / 2)
+    ys, xs = np.mgrid[0:H, 0:W]
+    n_extra = n_lists = 0
+    for trial in range(300):
+        l1 = 10.0 ** rng.uniform(1.0, 3.9)                       # variances: sigma from 3 to 90 px
+        l2 = l1 * 10.0 ** rng.uniform(-3.5, 0.0)
+        th = rng.uniform(0, np.pi)
+        c, s_ = np.cos(th), np.sin(th)
+        cov = np.array([[c * c * l1 + s_ * s_ * l2, c * s_ * (l1 - l2)], [c * s_ * (l1 - l2), s_ * s_ * l1 + c * c * l2]])
+        K = np.linalg.inv(cov)
+        u, v = rng.uniform(-40, W + 40), rng.uniform(-40, H + 40)
+        a11, a12, a22 = np.float32(K[0, 0]), np.float32(K[0, 1]), np.float32(K[1, 1])
+        D = float(a11) * float(a22) - float(a12) ** 2
+        if D <= 0:
+            continue
+        ex, ey = np.sqrt(6.25 * float(a22) / D) * 1.0001 + 0.01, np.sqrt(6.25 * float(a11) / D) * 1.0001 + 0.01
+        lo_u, hi_u, lo_v, hi_v = np.floor(u - ex), np.floor(u + ex), np.floor(v - ey), np.floor(v + ey)
+        if hi_u < 0 or lo_u > W - 1 or hi_v < 0 or lo_v > H - 1:
+            continue
+        bx0, bx1 = int(np.clip(lo_u, 0, W - 1)) // 16, int(np.clip(hi_u, 0, W - 1)) // 16
+        by0, by1 = int(np.clip(lo_v, 0, H - 1)) // 8, int(np.clip(hi_v, 0, H - 1)) // 8
+        h = by1 - by0 + 1
+        xa, xb = np.zeros(h, np.int32), np.zeros(h, np.int32)
+        r16 = np.array([u, v, a11, a12, a22, 0.5, ex, ey], np.float32)
+        hm.hm_row_spans(_ptr(r16), C.c_uint32(bx0 | (by0 << 16)), C.c_uint32(bx1 | (by1 << 16)), C.byref(view), _ptr(xa), _ptr(xb))
+        du, dv = xs - float(np.float32(u)), ys - float(np.float32(v))
+        q = float(a11) * du * du + 2 * float(a12) * du * dv + float(a22) * dv * dv
+        inside = q <= 6.25
+        loose = q <= 6.25 * 1.01 + 0.5                            # the padded region, generously
+        for r in range(h):
+            band = slice((by0 + r) * 8, (by0 + r) * 8 + 8)
+            cols = np.nonzero(inside[band].any(0))[0]
+            if len(cols):
+                assert xa[r] <= cols.min() // 16 and xb[r] >= cols.max() // 16, (trial, r, xa[r], xb[r], cols.min() // 16, cols.max() // 16)
+            if xb[r] >= xa[r]:
+                lc = np.nonzero(loose[band].any(0))[0]
+                n_lists += xb[r] - xa[r] + 1
+                if len(lc):
+                    n_extra += max(0, lc.min() // 16 - xa[r]) + max(0, xb[r] - lc.max() // 16)
+                else:
+                    n_extra += xb[r] - xa[r] + 1
+    assert n_lists > 3000 and n_extra <= 0.05 * n_lists, (n_lists, n_extra)

@@ -53,6 +53,7 @@ def simulate(config=3, n_lists=400, seed=0):
     pairs = {k: 0 for k in tot}
     entries = chunks = 0
     chunks_base = 0
+    inside_base = 0
     chunks_pool = {}
     px = np.arange(16)[None, :].repeat(8, 0).reshape(-1).astype(np.float64)
     py = np.arange(8)[:, None].repeat(16, 1).reshape(-1).astype(np.float64)
@@ -112,6 +113,7 @@ def simulate(config=3, n_lists=400, seed=0):
                     take = max(int(over[0]), 1)
                     mm = mm[:take]
                 lens = mm.sum(0)
+                inside[0] += int((qq[base:base + take] <= CHI).sum())           # lane evaluations that land inside the ellipse
                 it += int(lens.max())
                 pr += int(lens.sum())
                 qtot += lens
@@ -124,8 +126,10 @@ def simulate(config=3, n_lists=400, seed=0):
                 nch[0] += 1
             return it, pr, int(qtot.max())
         nch = [0]
+        inside = [0]
         i0, p0, f0 = run(m44, sub44, 8, False)
         chunks_base += nch[0]
+        inside_base += inside[0]
         for pl in (128, 160, 192, 10 ** 9):
             nch = [0]
             ip, pp, _ = run(m44, sub44, 8, False, pool=pl)
@@ -152,6 +156,15 @@ def simulate(config=3, n_lists=400, seed=0):
     print(f"config {config}: {nl} lists sampled of {lists_x * lists_y}; entries {entries} (-> P_b ~ {entries * scale_up / 1e6:.2f} M)")
     b = tot["base"]
     print(f"  chunks: base (queue cap {QCAP}) {chunks_base * scale_up / 1e3:.1f} K; " + "; ".join(f"{k} {v * scale_up / 1e3:.1f} K" for k, v in chunks_pool.items()))
+    useful = inside_base / max(tot["base"] * 128, 1)
+    print(f"  base: (pixel, Gaussian) evaluations inside the ellipse {inside_base * scale_up / 1e6:.1f} M of {tot['base'] * 128 * scale_up / 1e6:.1f} M lane "
+          f"evaluations = useful-lane fraction {useful:.3f}")
+    if len(sys.argv) > 3:
+        import json
+        json.dump({"config": config, "lists_sampled": nl, "iterations": tot["base"] * scale_up, "chunks": chunks_base * scale_up,
+                   "subtile_pairs": pairs["base"] * scale_up, "inside_evaluations": inside_base * scale_up, "useful_lane_fraction": useful,
+                   "queue_imbalance": tot["base"] * 8 / max(pairs["base"], 1),
+                   "variants_iterations_vs_base": {k: tot[k] / b for k in tot}}, open(sys.argv[3], "w"), indent=1)
     for k in tot:
         nq = 16 if k.startswith("4x2") else 8
         print(f"  {k:9s} iterations {tot[k]:9d} ({tot[k] * scale_up / 1e6:6.3f} M scaled)  = {tot[k] / b:5.3f} x base   "
