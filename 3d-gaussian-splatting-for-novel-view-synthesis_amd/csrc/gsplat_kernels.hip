@@ -297,13 +297,17 @@ __device__ __forceinline__ bool rect_is_big(u2 rect) {
 
 // Calls f(list, ordinal, a, b) for every list of a Gaussian's rectangle whose mask bit is set (row-major; ordinal 0 .. nt - 1
 // counts the calls; a, b = the owning lane's values).  Rectangles of up to 32 lists only: each lane walks its own.  Larger ones
-// (large Gaussians) are walked row by row by whole waves: for_each_big_row.
+// (large Gaussians) are walked row by row by whole waves (for_each_big_row): the caller passes nt = 0 for them.
 template <class F>
 __device__ __forceinline__ void for_each_list(u2 rect, uint32_t nt, uint32_t mask, int lists_x, int lane, uint64_t a, uint32_t b, F f) {
     const int x0 = rect.x & 0xFFFF, y0 = rect.x >> 16, x1 = rect.y & 0xFFFF, y1 = rect.y >> 16;
-    if (nt && !rect_is_big(rect)) {
+    if (nt) {                                  // (load_block_pairs leaves nt = 0 for a large Gaussian)
         uint32_t k = 0, m = mask;
+        // (left to itself the compiler, knowing the rectangle has at most 32 lists here, unrolls the walk into chains of predicated
+        //  LDS atomics: 2 us slower in bin_count_kernel at config 3 than the plain loops)
+#pragma clang loop unroll(disable)
         for (int y = y0; y <= y1; ++y)
+#pragma clang loop unroll(disable)
             for (int x = x0; x <= x1; ++x, m >>= 1)
                 if (m & 1u) f((uint32_t)(y * lists_x + x), k++, a, b);
     }
@@ -560,6 +564,8 @@ __device__ __forceinline__ BlockPairs load_block_pairs(int64_t n, const u2* __re
         const bool in = i < n;
         bp.nt[k] = in ? tiles[i] : 0u;
         bp.r[k] = in ? rect[i] : u2{0u, 0u};
+        if (rect_is_big(bp.r[k])) bp.nt[k] = 0u;           // a large Gaussian: binned by the big blocks (the rectangle of a Gaussian that is
+                                                           // not binned at all is stale, its nt is 0 anyway)
         bp.mk[k] = in ? mask[i] : 0u;
         dz[k] = (in && depth) ? depth[i] : 0.f;
     }
