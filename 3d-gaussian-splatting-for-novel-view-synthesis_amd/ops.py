@@ -182,9 +182,18 @@ class StageTimer:
     """Optional per-stage timing with HIP events recorded on the stream the kernels are launched on (torch's current
     stream).  bench.py installs one with `set_stage_timer`; when none is installed the hooks cost nothing."""
 
-    def __init__(self, only=None):
+    def __init__(self, only=None, every=1):
         self.events = []          # (stage, start_event, end_event)
         self.only = set(only) if only else None      # restrict to these stages (every event pair costs ~10 us of stream time)
+        self.every = max(1, int(every))              # ... and to every n-th pass (the passes in between run exactly as without a timer)
+        self.passes = 0
+
+    def wants(self, stages):
+        """Does this pass bracket any of `stages`?  (asked ONCE per pass and direction by the render op; counts the passes)"""
+        if self.only is not None and not (self.only & stages):
+            return False
+        self.passes += 1
+        return (self.passes - 1) % self.every == 0
 
     def totals_ms(self):
         """stage -> (launches, total milliseconds); call after a device synchronise."""
@@ -401,7 +410,7 @@ def _forward_begin(fused, view, c2w, pos, opacity_raw, a, b, c, d, need_grad=Fal
     chk = _deferred_stack[-1] if deferred else None
     pinned, slot = _ws.next_pinned(dev, key, chk)
     ready = _ws.get_event(dev, fresh=deferred, key=key)
-    wants_stages = _timer is not None and (_timer.only is None or _timer.only & _FORWARD_STAGES)
+    wants_stages = _timer is not None and _timer.wants(_FORWARD_STAGES)
     if deferred and _composite and not wants_stages:
         # ---- the whole forward pass in one call, on one arena
         H, W = view.H, view.W
@@ -566,7 +575,7 @@ def _backward_impl(fr, grad_image):
         fr.dirty = True                        # a second backward through the same graph must not reuse a dirty buffer
         args = (fr.gaussians, fr.c2w.data_ptr(), fr.view, fr.arena.data_ptr(), fr.arena.numel(), fr.n_pairs, gi.data_ptr(), gg)
         dargs = (det.data_ptr() if det is not None else None, det.numel() if det is not None else 0)
-        wants_stages = _timer is not None and (_timer.only is None or _timer.only & _BACKWARD_STAGES)
+        wants_stages = _timer is not None and _timer.wants(_BACKWARD_STAGES)
         if factored or wants_stages:
             glogit = torch.empty((fr.n, 3), dtype=torch.float32, device=dev) if factored else None
             with _stage("raster_backward"):
