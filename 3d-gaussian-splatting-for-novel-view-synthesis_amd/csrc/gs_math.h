@@ -53,6 +53,17 @@ constexpr int LIST_W = 16, LIST_H = 8;
 
 enum : int { VIS_OK = 0, VIS_CULLED = 1, VIS_OFFSCREEN = 2 };
 
+// 1 / x and sqrt(x) to 1 ulp in ONE instruction on the device (v_rcp_f32, v_sqrt_f32), used where nothing the image or the reference's
+// integer outputs depend on is computed: padded extents and masks, gradient-only terms.  (An IEEE division is ~10 instructions, and
+// the projection kernel had 35 of them.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GS_RCP_FAST(x) __builtin_amdgcn_rcpf(x)
+#define GS_SQRT_FAST(x) __builtin_amdgcn_sqrtf(x)
+#else
+#define GS_RCP_FAST(x) (1.0f / (x))
+#define GS_SQRT_FAST(x) sqrtf(x)
+#endif
+
 GS_HD float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 GS_HD float clampf_(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
@@ -246,10 +257,10 @@ GS_HD void sh_basis_grad(const ShMid& m, const float dY[16], float dd[3]) {
 
 // d = v / (n + eps), v = p - eye: gradient w.r.t. the direction -> gradient w.r.t. the point.
 GS_HD void sh_dir_to_point(const ShMid& m, const float dd[3], float g_p[3]) {
-    const float ne = m.n + 1e-8f;
+    const float ne = m.n + 1e-8f, ine = GS_RCP_FAST(ne);
     const float dot = dd[0] * m.v[0] + dd[1] * m.v[1] + dd[2] * m.v[2];
-    const float c = (m.n > 0.f) ? dot / (m.n * ne * ne) : 0.f;
-    for (int k = 0; k < 3; ++k) g_p[k] = dd[k] / ne - m.v[k] * c;
+    const float c = (m.n > 0.f) ? dot * GS_RCP_FAST(m.n * ne * ne) : 0.f;
+    for (int k = 0; k < 3; ++k) g_p[k] = dd[k] * ine - m.v[k] * c;
 }
 
 // B3 (colour part).  g_rgb = dL/d colour.  Emits dL/dcoef through `emit(k, ch, value)`; returns dL/dp in g_p.
@@ -360,18 +371,14 @@ struct BigSpanK {               // per-Gaussian constants of big_row_span
 GS_HD void big_span_constants(float A11, float A12, float A22, float ex, float chi_pad, float out[4]) {
     const float D = A11 * A22 - A12 * A12;
     const bool pd = (D > 0.f) && (A11 > 0.f) && (A22 > 0.f) && (ex < 1e30f);
-    out[0] = -A12 / A11; out[1] = pd ? chi_pad / A11 : -1.f; out[2] = D / (A11 * A11); out[3] = (A12 / A22) * ex;
+    const float i11 = GS_RCP_FAST(A11), i22 = GS_RCP_FAST(A22);
+    out[0] = -A12 * i11; out[1] = pd ? chi_pad * i11 : -1.f; out[2] = D * i11 * i11; out[3] = A12 * i22 * ex;
 }
 GS_HD BigSpanK big_span_setup(float u, float v, float ex, float ey, const float k4[4], int bx0, int bx1) {
     BigSpanK k;
     k.u = u; k.v = v; k.ex = ex; k.ey = ey; k.c = k4[0]; k.k0 = k4[1]; k.k1 = k4[2]; k.ts = k4[3]; k.bx0 = bx0; k.bx1 = bx1;
     return k;
 }
-#if defined(__HIP_DEVICE_COMPILE__)
-#define GS_SQRT_FAST(x) __builtin_amdgcn_sqrtf(x)      // v_sqrt_f32 (1 ulp): the spans are padded by 0.02 px, and every kernel uses the same one
-#else
-#define GS_SQRT_FAST(x) sqrtf(x)
-#endif
 GS_HD RowSpan big_row_span(const BigSpanK& k, int y) {
     if (!(k.k0 >= 0.f)) return RowSpan{k.bx0, k.bx1};
     const float d0 = (float)(y * LIST_H) - k.v - 0.02f, d1 = (float)(y * LIST_H + LIST_H - 1) - k.v + 0.02f;
@@ -395,7 +402,7 @@ GS_HD uint32_t binned_mask(const Proj& o, const ViewK& vk) {
     if (o.bx1 < o.bx0 || o.by1 < o.by0) return 0u;
     const int w = o.bx1 - o.bx0 + 1, h = o.by1 - o.by0 + 1;
     if (w * h > 32 || !(o.A11 > 0.f && o.A22 > 0.f)) return 0xFFFFFFFFu >> (w * h > 32 ? 0 : 32 - w * h);
-    const float chi_pad = vk.chi_clip * 1.001f + 1e-4f, r12_22 = -o.A12 / o.A22, r12_11 = -o.A12 / o.A11;
+    const float chi_pad = vk.chi_clip * 1.001f + 1e-4f, r12_22 = -o.A12 * GS_RCP_FAST(o.A22), r12_11 = -o.A12 * GS_RCP_FAST(o.A11);
     uint32_t m = 0u;
     int k = 0;
     for (int y = o.by0; y <= o.by1; ++y)
@@ -495,8 +502,9 @@ GS_HD void project_gaussian(const float p[3], const float S[6], float o_raw, con
     {
         const float D = o.A11 * o.A22 - o.A12 * o.A12;
         if (D > 0.f && o.A11 > 0.f && o.A22 > 0.f) {
-            o.ex = sqrtf(vk.chi_clip * o.A22 / D) * 1.0001f + 0.01f;
-            o.ey = sqrtf(vk.chi_clip * o.A11 / D) * 1.0001f + 0.01f;
+            const float cd = vk.chi_clip * GS_RCP_FAST(D);
+            o.ex = GS_SQRT_FAST(cd * o.A22) * 1.0001f + 0.01f;
+            o.ey = GS_SQRT_FAST(cd * o.A11) * 1.0001f + 0.01f;
             if (!(o.ex < 1e30f)) o.ex = 1e30f;
             if (!(o.ey < 1e30f)) o.ey = 1e30f;
         } else {
