@@ -14,7 +14,7 @@ GSPLAT_OK = 0
 GSPLAT_SCENE_OK = 0
 GSPLAT_SCENE_ALL_CULLED = 10
 GSPLAT_SCENE_ALL_OFFSCREEN = 11
-ABI_VERSION = 5
+ABI_VERSION = 6
 GSPLAT_PROJECT_COLOUR_FUSED = 1
 GSPLAT_PROJECT_COUNTS_MAPPED = 2
 GSPLAT_PROJECT_SAVE_SH_JACOBIAN = 4
@@ -80,7 +80,7 @@ SIGNATURES = {
     "gsplat_build_sigma_backward": (_INT, [_I64, _VP, _VP, _VP, _VP, _VP, _VP]),
     "gsplat_evaluate_sh": (_INT, [_I64, _VP, _VP, _VP, _VP, _VP, _VP]),
     "gsplat_evaluate_sh_backward": (_INT, [_I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
-    "gsplat_loss_scratch_bytes": (_I64, []),
+    "gsplat_loss_scratch_bytes": (_I64, [_I64, C.c_int32, C.c_int32, C.c_int32]),
     "gsplat_loss": (_INT, [_VP, _VP, _I64, C.c_int32, C.c_int32, C.c_float, C.c_float, _VP, _VP, _VP, _VP]),
     "gsplat_clip_scratch_bytes": (_I64, []),
     "gsplat_clip_grad_norm": (_INT, [_I64, _VP, C.c_float, _VP, _VP, _VP]),

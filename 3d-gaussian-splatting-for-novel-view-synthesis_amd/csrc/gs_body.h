@@ -90,14 +90,11 @@ struct GradOut {            // what K8 stores for one Gaussian
 // K1 core, part 1: everything except the colour.
 GS_HD Proj project_geometry(const GaussIn& in, bool fused, const Camera& cam, const ViewK& vk) {
     float S[6];
-    if (fused) {
-        CovMid cm;
-        cov_from_params(in.sr, in.qr, S, cm);
-    } else {
-        load_cov6(in.S9, S);
-    }
+    CovMid cm;
+    if (fused) cov_from_params(in.sr, in.qr, S, cm);
+    else load_cov6(in.S9, S);
     Proj o; ProjMid m;
-    project_gaussian(in.p, S, in.o_raw, cam, vk, o, m);
+    project_gaussian(in.p, S, in.o_raw, cam, vk, o, m, fused ? &cm : nullptr);
     return o;
 }
 
@@ -170,7 +167,7 @@ GS_HD GradOut project_backward_core(const GaussIn& in, bool fused, Coef coef, Em
         if (fused) cov_from_params(in.sr, in.qr, S, cm);
         else load_cov6(in.S9, S);
         Proj o; ProjMid m;
-        project_gaussian(in.p, S, in.o_raw, cam, vk, o, m);
+        project_gaussian(in.p, S, in.o_raw, cam, vk, o, m, fused ? &cm : nullptr);
         float gu = r9[0], gv = r9[1], ga = r9[2], gb = r9[3], gc = r9[4];
         if (moments) {
             gu = o.opacity * (o.A11 * r9[0] + o.A12 * r9[1]);

@@ -413,8 +413,12 @@ GS_HD uint32_t binned_mask(const Proj& o, const ViewK& vk) {
     return m;
 }
 
+// cmid (nullable): the scales and the rotation S was built from (fused inputs).  With them the determinant of the 2-D covariance is
+// formed WITHOUT the cancellation of a d - b^2 (a needle seen along its length: eigenvalues 0.17 and 1200 px^2 lose 4 digits there,
+// and the conic -- its entries are entries of the covariance over the determinant -- with them):
+//   det(J C J^T) = n^T adj(C) n,  n = j0 x j1,  C = Q diag(s^2) Q^T (Q = W R)  =>  det = sum_k (s_i s_j (Q^T n)_k)^2,  a sum of squares.
 GS_HD void project_gaussian(const float p[3], const float S[6], float o_raw, const Camera& cam, const ViewK& vk, Proj& o,
-                            ProjMid& m) {
+                            ProjMid& m, const CovMid* cmid = nullptr) {
     o.vis = VIS_CULLED;
     o.tx0 = o.ty0 = 0; o.tx1 = o.ty1 = -1;
     o.bx0 = o.by0 = 0; o.bx1 = o.by1 = -1; o.bmask = 0u; o.btiles = 0;
@@ -467,6 +471,18 @@ GS_HD void project_gaussian(const float p[3], const float S[6], float o_raw, con
     m.diff = 0.5f * (m.a - m.d);
     m.rad = sqrtf(m.diff * m.diff + m.b * m.b);
     m.l1 = mid + m.rad; m.l2 = mid - m.rad;
+    float det_exact = -1.f;                                                          // (< 0: not available)
+    if (cmid) {
+        const float n0 = -m.j02 * m.j11, n1 = -m.j00 * m.j12, n2 = m.j00 * m.j11;    // j0 x j1
+        const float t0 = w[0] * n0 + w[3] * n1 + w[6] * n2, t1 = w[1] * n0 + w[4] * n1 + w[7] * n2, t2 = w[2] * n0 + w[5] * n1 + w[8] * n2;
+        const float* R = cmid->R;
+        const float e0 = cmid->s[1] * cmid->s[2] * (R[0] * t0 + R[3] * t1 + R[6] * t2);
+        const float e1 = cmid->s[0] * cmid->s[2] * (R[1] * t0 + R[4] * t1 + R[7] * t2);
+        const float e2 = cmid->s[0] * cmid->s[1] * (R[2] * t0 + R[5] * t1 + R[8] * t2);
+        det_exact = e0 * e0 + e1 * e1 + e2 * e2;
+        if (m.l1 > 1e-30f && det_exact < 3e38f) m.l2 = det_exact / m.l1;            // the small eigenvalue without mid - rad
+        else det_exact = -1.f;
+    }
     m.f1 = clampf_(m.l1, 1e-6f, 1e4f); m.f2 = clampf_(m.l2, 1e-6f, 1e4f);
     m.clamped = (m.f1 != m.l1) || (m.f2 != m.l2);
     float a2, b2, d2;        // (locals, stored once: stores to m inside the branches were merged into a store through a pointer phi,
@@ -490,7 +506,8 @@ GS_HD void project_gaussian(const float p[3], const float S[6], float o_raw, con
     const float r = ceilf(2.5f * sqrtf(lam));
     const float umin = floorf(o.u - r), umax = floorf(o.u + r), vmin = floorf(o.v - r), vmax = floorf(o.v + r);
     // F13 conic
-    m.det = m.a2 * m.d2 - m.b2 * m.b2;
+    // (after the clamp the recomposed matrix has the eigenvalues f1, f2 by construction: their product, not a2 d2 - b2^2)
+    m.det = m.clamped ? (m.rad > 0.f ? m.f1 * m.f2 : m.f1 * m.f1) : (det_exact >= 0.f ? det_exact : m.a2 * m.d2 - m.b2 * m.b2);
     m.sdet = fmaxf(m.det, 1e-12f);
     m.i00 = m.d2 / m.sdet; m.i11 = m.a2 / m.sdet;
     o.A11 = fmaxf(m.i00, vk.min_conis);

@@ -33,7 +33,7 @@ class _LossFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             values = torch.empty(3, dtype=torch.float32, device=dev)
             grad = torch.empty_like(x) if need else None
-            scratch = torch.empty(lib.gsplat_loss_scratch_bytes(), dtype=torch.uint8, device=dev)
+            scratch = torch.empty(lib.gsplat_loss_scratch_bytes(b, h, w, 1 if need else 0), dtype=torch.uint8, device=dev)
             with _stage("loss"):
                 _abi.check(lib.gsplat_loss(_p(x), _p(y), b, h, w, float(l1w), float(sw), _p(values), _p(grad), _p(scratch),
                                            _stream_ptr(dev)), "gsplat_loss")

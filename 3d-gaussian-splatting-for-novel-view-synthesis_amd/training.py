@@ -50,6 +50,13 @@ class TrainConfig:
     scale_threshold: float = 0.01
     checkpoint_interval: int = 1000
     densify_seed: int = 0
+    # not a reference hyper-parameter: the views of one iteration alternate between this many HIP streams (1 or 2), so that the
+    # latency-bound front of view k + 1 (projection, binning) runs beside the VALU-bound rasterisation of view k: ~10 % per view
+    # at config 3.  Gradients accumulate in view order either way.
+    view_streams: int = 2
+
+
+_side_streams = {}           # per device: the two streams the views of an iteration alternate between (TrainConfig.view_streams)
 
 
 class Trainer:
@@ -68,6 +75,18 @@ class Trainer:
         groups = optim.reference_param_groups(self.model, position_lr_init=pos_lr, feature_lr=c.feature_lr,
                                               opacity_lr=c.opacity_lr, scaling_lr=c.scaling_lr, rotation_lr=c.rotation_lr)
         return optim.GaussianAdam(groups, lr=c.lr, eps=1e-15)
+
+    def _view_streams(self, dev):
+        key = (dev.type, dev.index)
+        got = _side_streams.get(key)
+        if got is None:
+            got = _side_streams[key] = tuple(torch.cuda.Stream(dev) for _ in range(2))
+            # the parameters' AccumulateGrad nodes live on the caller's stream and the views' backward passes on the side streams: that
+            # is the point (the engine orders the two); torch would warn about it in every iteration
+            quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+            if quiet is not None:
+                quiet(False)
+        return got
 
     def _world(self):
         if dist.is_available() and dist.is_initialized():
@@ -107,13 +126,26 @@ class Trainer:
             pass_error = None
             try:
                 with ops.deferred_checks() as checks, (exchange if exchange is not None else contextlib.nullcontext()):
-                    for v in views:                                                    # (the gradient sink is always removed again)
-                        image_gt = torch.as_tensor(v['image']).to(dev)
-                        c2w = torch.as_tensor(v['c2w'], dtype=torch.float32).to(dev)
-                        rendered = ops.render_gaussians(m.pos, m.f_dc, m.f_rest, m.opacity_raw, m.scale_raw, m.q_raw, c2w,
-                                                        int(v['H']), int(v['W']), float(v['fx']), float(v['fy']), float(v['cx']), float(v['cy']))
-                        loss, vals = losses.compute_loss_device(rendered, image_gt, c.lambda_l1, c.lambda_ssim)
-                        (loss / n_global).backward()
+                    side = self._view_streams(dev) if (c.view_streams > 1 and len(views) > 1 and world == 1) else ()     # (one process: the
+                    # exchange's collectives of a data-parallel pass stay on the caller's stream)
+                    main = torch.cuda.current_stream(dev) if side else None
+                    for st in side:
+                        st.wait_stream(main)                                           # parameters, zeroed gradients
+                    per_view = []
+                    for k, v in enumerate(views):                                      # (the gradient sink is always removed again)
+                        with (torch.cuda.stream(side[k % len(side)]) if side else contextlib.nullcontext()):
+                            image_gt = torch.as_tensor(v['image']).to(dev)
+                            c2w = torch.as_tensor(v['c2w'], dtype=torch.float32).to(dev)
+                            rendered = ops.render_gaussians(m.pos, m.f_dc, m.f_rest, m.opacity_raw, m.scale_raw, m.q_raw, c2w,
+                                                            int(v['H']), int(v['W']), float(v['fx']), float(v['fy']), float(v['cx']), float(v['cy']))
+                            loss, vals = losses.compute_loss_device(rendered, image_gt, c.lambda_l1, c.lambda_ssim)
+                            (loss / n_global).backward()
+                            per_view.append(vals)
+                    for st in side:
+                        main.wait_stream(st)
+                    for vals in per_view:                                              # (on the caller's stream, in view order)
+                        if side:
+                            vals.record_stream(main)
                         acc += vals / n_global
             except Exception as e:                # single process: nothing to agree on, the exception leaves as it is
                 if world == 1:

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GSPLAT_ABI_VERSION 5
+#define GSPLAT_ABI_VERSION 6
 
 /* call status */
 #define GSPLAT_OK 0
@@ -259,8 +259,9 @@ int gsplat_evaluate_sh_backward(int64_t n, const float* f_dc, const float* f_res
  * compute_loss() of the reference (gaussian_splatting/losses.py:158-185; l1_loss :27, ssim_loss :44,
  * 11 x 11 Gaussian window, sigma 1.5, zero padding): lambda_l1 * mean|pred - target| + lambda_ssim * (1 - SSIM).
  * pred/target/grad_pred are [batch, H, W, 3] fp32 device arrays.  values[3] (device) receives (l1, 1 - ssim, total);
- * grad_pred (nullable) receives d total / d pred.  scratch: gsplat_loss_scratch_bytes() device bytes.            */
-int64_t gsplat_loss_scratch_bytes(void);
+ * grad_pred (nullable) receives d total / d pred.  scratch: gsplat_loss_scratch_bytes(batch, H, W, grad_pred != NULL) device
+ * bytes (the partial sums, and -- with a gradient -- the three partial-derivative maps of the SSIM term, 36 B per value).   */
+int64_t gsplat_loss_scratch_bytes(int64_t batch, int32_t H, int32_t W, int32_t with_grad);
 int gsplat_loss(const float* pred, const float* target, int64_t batch, int32_t H, int32_t W, float lambda_l1,
                 float lambda_ssim, float* values, float* grad_pred, void* scratch, void* stream);
 

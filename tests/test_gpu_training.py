@@ -229,6 +229,31 @@ def test_trainer_step_does_not_wait_per_view_in_steady_state():
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
 
 
+def test_views_on_two_streams_train_like_views_on_one():
+    """TrainConfig.view_streams: the views of an iteration alternate between two HIP streams (the front of view k + 1 beside the
+    rasterisation of view k).  With deterministic gradients the parameters after three iterations are bit-identical to the
+    one-stream loop's: same kernels, same accumulation order."""
+    model_mod = importlib.import_module(PKG + ".model")
+    training = importlib.import_module(PKG + ".training")
+    ops = importlib.import_module(PKG + ".ops")
+    s, views = _scene()
+    views = views + views[::-1]                                  # four views per iteration
+    ops.set_deterministic(True)
+    try:
+        out = []
+        for streams in (1, 2):
+            model = model_mod.GaussianModel({k: torch.tensor(s[k]) for k in NAMES}, device="cuda:0")
+            tr = training.Trainer(model, training.TrainConfig(densify_until_iter=0, opacity_reset_interval=10 ** 9, view_streams=streams))
+            losses = [float(tr.step(it, views)["loss"]) for it in (1, 2, 3)]
+            torch.cuda.synchronize()
+            out.append((losses, {k: getattr(model, k).detach().clone() for k in NAMES}))
+    finally:
+        ops.set_deterministic(False)
+    assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+    for k in NAMES:
+        assert torch.equal(out[0][1][k], out[1][1][k]), k
+
+
 def test_config4_training_iteration():
     """BASELINE.json config 4 as it says: the 3 M-Gaussian scene at 1080p through Trainer.step (render + L1/SSIM loss + backward
     + clip + Adam), two views.  Finite, every parameter moves, and the loss of view 0 equals the oracle's compute_loss of the

@@ -279,6 +279,43 @@ def test_rotation_gradient_of_near_isotropic_gaussians_is_cancellation_free(hm):
     assert np.linalg.norm(gq - b.grad.numpy()) / np.linalg.norm(b.grad.numpy()) <= 1e-4
 
 
+def test_conic_of_needle_gaussians_has_no_determinant_cancellation(hm):
+    """A Gaussian 100 x longer than wide projects to a 2-D covariance whose determinant a d - b^2 cancels 4 digits in float32 (stress
+    seed 794: eigenvalues 0.17 and 1200 px^2; the reference's own fp32 conic is 9e-5 off there, a d - b^2 here was 5e-4 off).
+    With the fused inputs the determinant is the sum of squares sum_k (s_i s_j (Q^T n)_k)^2: the conic is good to a few ulp at
+    every aspect ratio.  The float32 oracle is timed beside it: the bound is not one the reference's arithmetic meets."""
+    rng = np.random.default_rng(7)
+    n = 3000
+    H, W, fx = 200, 300, 250.0
+    for aspect_log, bound in ((2.0, 2e-5), (4.0, 2e-5), (5.0, 2e-5)):
+        pos = np.concatenate([rng.uniform(-1.0, 1.0, (n, 2)), rng.uniform(3.0, 6.0, (n, 1))], 1).astype(np.float32)
+        sr = rng.normal(-4.0, 0.3, (n, 3)).astype(np.float32)
+        sr[np.arange(n), rng.integers(0, 3, n)] += aspect_log                  # one long axis
+        arrs = dict(pos=pos, scale_raw=sr, q_raw=rng.normal(0, 1, (n, 4)).astype(np.float32), opacity_raw=rng.normal(1, 1, n).astype(np.float32),
+                    f_dc=rng.normal(0, 1, (n, 3)).astype(np.float32), f_rest=np.zeros((n, 45), np.float32))
+        d = dict(c2w=np.eye(4, dtype=np.float32), H=H, W=W, fx=fx, fy=fx, cx=W / 2, cy=H / 2, kwargs={})
+        rec, tiles, vis, *_ = _project(hm, d, arrs)
+        res = {}
+        for tag, dt in (("f64", torch.float64), ("f32", torch.float32)):
+            st = {}
+            tp.render_fused(*[torch.tensor(arrs[k]).to(dt) for k in ("pos", "f_dc", "f_rest", "opacity_raw", "scale_raw", "q_raw")],
+                            torch.eye(4, dtype=dt), H, W, fx, fx, W / 2, H / 2, stages=st, stop_after_binning=True)
+            res[tag] = (st["ids"].numpy(), st["conic"].double().numpy(), st["evals"].double().numpy())
+        ids, con, ev = res["f64"]
+        inside = (ev[:, 0] > 2e-6) & (ev[:, 1] < 0.99e4)                        # the eigen clamp is a different matter (F8)
+        assert inside.sum() > n // 8 and (ev[inside, 1] / ev[inside, 0]).max() > 10 ** (0.8 * aspect_log)
+        mine = np.stack([rec[0][ids, 2], rec[0][ids, 3], rec[1][ids, 0]], 1).astype(np.float64)
+        err = (np.abs(mine - con).max(1) / np.abs(con).max(1))[inside]
+        assert err.max() <= bound, (aspect_log, err.max())
+        ids32, con32, _ = res["f32"]
+        common = np.intersect1d(ids[inside], ids32)
+        e32 = np.abs(con32[np.searchsorted(ids32, common) if np.all(np.diff(ids32) > 0) else [list(ids32).index(i) for i in common]] -
+                     con[[list(ids).index(i) for i in common]]).max(1) / np.abs(con[[list(ids).index(i) for i in common]]).max(1)
+        print(aspect_log, "host build", err.max(), "float32 oracle", e32.max(), "largest condition number", (ev[inside, 1] / ev[inside, 0]).max())
+        if aspect_log >= 4.0:
+            assert e32.max() > 10 * err.max(), (aspect_log, e32.max(), err.max())
+
+
 def test_row_spans_of_large_gaussians_cover_every_pixel_inside_the_ellipse(hm):
     """gs_math.h big_row_span against brute force on random large ellipses (blobs and thin rotated needles, centres on and off the
     grid): every list of every row that holds a pixel centre with q <= chi lies inside the row's span, and the spans are tight (a
