@@ -14,7 +14,7 @@ GSPLAT_OK = 0
 GSPLAT_SCENE_OK = 0
 GSPLAT_SCENE_ALL_CULLED = 10
 GSPLAT_SCENE_ALL_OFFSCREEN = 11
-ABI_VERSION = 6
+ABI_VERSION = 7
 GSPLAT_PROJECT_COLOUR_FUSED = 1
 GSPLAT_PROJECT_COUNTS_MAPPED = 2
 GSPLAT_PROJECT_SAVE_SH_JACOBIAN = 4
@@ -46,6 +46,11 @@ class Gaussians(C.Structure):
 class GaussianGrads(C.Structure):
     _fields_ = [("pos", C.c_void_p), ("opacity_raw", C.c_void_p), ("color", C.c_void_p), ("sigma", C.c_void_p),
                 ("scale_raw", C.c_void_p), ("q_raw", C.c_void_p), ("f_dc", C.c_void_p), ("f_rest", C.c_void_p)]
+
+
+class AdamGroup(C.Structure):
+    _fields_ = [("n", C.c_int64), ("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("lr", C.c_float), ("step", C.c_int32), ("grad_scale", C.c_void_p)]
 
 
 class Counts(C.Structure):
@@ -85,6 +90,7 @@ SIGNATURES = {
     "gsplat_clip_scratch_bytes": (_I64, []),
     "gsplat_clip_grad_norm": (_INT, [_I64, _VP, C.c_float, _VP, _VP, _VP]),
     "gsplat_adam_step": (_INT, [_I64, _VP, _VP, _VP, _VP, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, _VP, _VP]),
+    "gsplat_adam_step_multi": (_INT, [C.c_int32, C.POINTER(AdamGroup), C.c_float, C.c_float, C.c_float, _VP]),
 }
 
 _lib = None

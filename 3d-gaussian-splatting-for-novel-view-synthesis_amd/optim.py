@@ -2,7 +2,7 @@
 
 Mirrors the call sites of scripts/train.py: `optim.Adam([...six groups...], lr=lr, eps=1e-15)` (:394-401), the position
 learning-rate schedule (:446-457), `clip_grad_norm_(model.pos, max_norm=1.0)` (:536) and `optimizer.step()` (:538).
-`GaussianAdam` takes torch-style param groups; `step()` runs one fused HIP kernel per tensor (csrc/gsplat_optim.hip); the
+`GaussianAdam` takes torch-style param groups; `step()` runs ONE fused HIP kernel for all of them (csrc/gsplat_optim.hip); the
 clip coefficient is computed and applied on the device, so a training step has no host synchronisation here.
 """
 import ctypes as C
@@ -89,20 +89,28 @@ class GaussianAdam:
 
     @torch.no_grad()
     def step(self):
+        """One launch per device for all parameter groups (gsplat_adam_step_multi, eight tensors per launch)."""
         lib = _abi.lib()
         pending = getattr(self, "_pending_clip", None)
+        per_device = {}
+        for g in self.param_groups:
+            for p in g['params']:
+                if p.grad is None:
+                    continue
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
+                    raise RuntimeError("GaussianAdam needs contiguous fp32 GPU parameters (there is no CPU fallback)")
+                st = self._state(p)
+                st['step'] += 1
+                scale = pending[1] if pending is not None and pending[0] is p else None
+                per_device.setdefault(p.device, []).append(
+                    _abi.AdamGroup(p.numel(), _p(p).value, _p(p.grad).value, _p(st['exp_avg']).value, _p(st['exp_avg_sq']).value,
+                                   float(g['lr']), int(st['step']), _p(scale).value if scale is not None else None))
         with _stage("adam"):
-            for g in self.param_groups:
-                for p in g['params']:
-                    if p.grad is None:
-                        continue
-                    if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()):
-                        raise RuntimeError("GaussianAdam needs contiguous fp32 GPU parameters (there is no CPU fallback)")
-                    st = self._state(p)
-                    st['step'] += 1
-                    scale = pending[1] if pending is not None and pending[0] is p else None
-                    with torch.cuda.device(p.device):
-                        _abi.check(lib.gsplat_adam_step(p.numel(), _p(p), _p(p.grad), _p(st['exp_avg']), _p(st['exp_avg_sq']),
-                                                        float(g['lr']), float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                                                        int(st['step']), _p(scale), _stream_ptr(p.device)), "gsplat_adam_step")
+            for dev, groups in per_device.items():
+                with torch.cuda.device(dev):
+                    for k in range(0, len(groups), 8):
+                        chunk = groups[k:k + 8]
+                        arr = (_abi.AdamGroup * len(chunk))(*chunk)
+                        _abi.check(lib.gsplat_adam_step_multi(len(chunk), arr, float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                                              _stream_ptr(dev)), "gsplat_adam_step_multi")
         self._pending_clip = None

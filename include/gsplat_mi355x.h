@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GSPLAT_ABI_VERSION 6
+#define GSPLAT_ABI_VERSION 7
 
 /* call status */
 #define GSPLAT_OK 0
@@ -275,6 +275,19 @@ int64_t gsplat_clip_scratch_bytes(void);
 int gsplat_clip_grad_norm(int64_t n, const float* grad, float max_norm, float* coef_and_norm, void* scratch, void* stream);
 int gsplat_adam_step(int64_t n, float* param, float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
                      float beta2, float eps, int32_t step, const float* grad_scale, void* stream);
+/* The same update for up to 8 tensors in ONE launch (the six parameter groups of scripts/train.py:394-401): group k is
+ * gsplat_adam_step(n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale) with its own lr / step.          */
+typedef struct gsplat_adam_group {
+    int64_t n;
+    float* param;
+    float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    float lr;
+    int32_t step;
+    const float* grad_scale;      /* nullable device scalar */
+} gsplat_adam_group;
+int gsplat_adam_step_multi(int32_t n_groups, const gsplat_adam_group* groups, float beta1, float beta2, float eps, void* stream);
 
 #ifdef __cplusplus
 }

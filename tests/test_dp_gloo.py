@@ -1,4 +1,5 @@
 """Data-parallel-by-view helper on CPU: world_size 2 over gloo (the GPU path uses the same code over RCCL)."""
+import datetime
 import importlib
 import os
 import socket
@@ -27,7 +28,7 @@ def _grads(rank):
 
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     dp = importlib.import_module(PKG + ".dp")
     grads = _grads(rank)
     dp.allreduce_gradients(grads, world_views=world)
@@ -108,7 +109,7 @@ def _factored_inputs(rank, n=257, views=None):
 
 def _factored_worker(rank, world, port, q, even=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     dp = importlib.import_module(PKG + ".dp")
     pos = torch.randn(257, 3, generator=torch.Generator().manual_seed(7))          # replicated parameters
     params = {k: torch.zeros(*s, requires_grad=True) for k, s in SHAPES.items()}
@@ -158,7 +159,7 @@ def test_factored_exchange_world2(even):
 
 def _uneven3_worker(rank, world, port, q, given):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     dp = importlib.import_module(PKG + ".dp")
     counts = (2, 1, 3)
     # what Trainer.step does first: every rank must come out with the same (equal, n_global)
@@ -214,7 +215,7 @@ def test_agree_on_views_rejects_inconsistent_hints():
 # ---- Trainer.step: one agreement per pass, whatever happens on a rank (host logic; the renderer is a toy: the HIP op needs a GPU) ----
 def _toy_trainer_worker(rank, world, port, q, mode):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     ops = importlib.import_module(PKG + ".ops")
     training = importlib.import_module(PKG + ".training")
     losses = importlib.import_module(PKG + ".losses")

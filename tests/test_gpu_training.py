@@ -1,6 +1,7 @@
 """Next row 2 end to end: training.Trainer.step against the same iteration written with the oracle
 (oracle/torch_port.py render + loss, float64) and torch.optim.Adam / clip_grad_norm_ at the reference's settings
 (scripts/train.py:394-401, 446-569)."""
+import datetime
 import importlib
 
 import numpy as np
@@ -114,7 +115,7 @@ def _dp_worker(rank, world, port, q):
     import os
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     model_mod = importlib.import_module(PKG + ".model")
     training = importlib.import_module(PKG + ".training")
     s, views = _scene()
@@ -142,7 +143,7 @@ def test_data_parallel_training_matches_single_process():
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = dict((r, (params, n)) for r, params, n in (q.get(timeout=300) for _ in range(2)))
+    got = dict((r, (params, n)) for r, params, n in (q.get(timeout=150) for _ in range(2)))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -205,7 +206,7 @@ def test_exchange_collectives_run_over_rccl():
     q = ctx.Queue()
     proc = ctx.Process(target=_rccl_worker, args=(port, q))
     proc.start()
-    res = q.get(timeout=300)
+    res = q.get(timeout=150)
     proc.join(timeout=120)
     assert proc.exitcode == 0
     for k in NAMES:
@@ -335,7 +336,7 @@ def _dp_offscreen_worker(rank, world, port, q):
     import os
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     model_mod = importlib.import_module(PKG + ".model")
     training = importlib.import_module(PKG + ".training")
     s = scenes.case_g10()                                        # 48 Gaussians whose centres project into the guard band LEFT of a 32 x 32 image
@@ -371,7 +372,7 @@ def test_an_offscreen_view_on_one_rank_raises_on_every_rank():
     procs = [ctx.Process(target=_dp_offscreen_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = dict((r, (name, msg)) for r, name, msg in (q.get(timeout=300) for _ in range(2)))
+    got = dict((r, (name, msg)) for r, name, msg in (q.get(timeout=150) for _ in range(2)))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
