@@ -321,7 +321,9 @@ def test_factored_sh_gradient_exchange_matches_the_plain_backward(gs):
     assert (g_rest.cpu().double() - acc[:, 1:, :].transpose(1, 2).reshape(n, 45)).abs().max() < 1e-5
 
 
-@pytest.mark.parametrize("seed", list(range(10)) + list(range(100, 150)) + [207, 339])      # (207, 339: the two of 400 further seeds that round 2 left outside the bounds)
+# (207, 339: the two of 400 further seeds that round 2 left outside the bounds; 794: the one of 769 that round 3's sweep found -- a
+#  needle whose conic lost four digits in a d - b^2, fixed in gs_math.h; asserted with the general bounds)
+@pytest.mark.parametrize("seed", list(range(10)) + list(range(100, 150)) + [207, 339, 794])
 def test_random_scenes_vs_oracle(gs, seed):
     """Randomised image sizes, cameras, anisotropies and opacities against the float64 oracle: exercises ragged list grids,
     partial coarse bins, masks of thin rotated ellipses, chunk and group boundaries of the binning and raster kernels."""
