@@ -20,6 +20,7 @@ Extra objects on the line:
   cpu_baseline  the CPU oracle (oracle/torch_port.py, the reference's PyTorch CPU path restated) timed on this box's
                 host cores on a bounded sample: a CROP of the frame (rank 0, N = 1 only).  A reported baseline, not the target.
   sustained     >= 1 s of back-to-back steps after the timed region: ms/step mean, min and max over 10 windows.
+  three_call_sequence  the same step through the reference's own three calls (build_sigma_from_params, evaluate_sh, render).
   waiting_path  the same step through the call that waits for every frame's pair count (the reference-style call).
   N = 1 extras  (outside the timed region; --no-extras skips them) forward_only (the reference's FPS protocol,
                 scripts/render_trained.py:319-381: frame by frame, and software-pipelined render_frames), train_step
@@ -578,6 +579,30 @@ def single_gpu_extras(gs, ops, params, cam, cam_args, dev, fence):
     out["forward_only"] = {"workload": "config 3, forward only, 32 orbit views (8 distinct poses)", "frame_by_frame_ms": ms_seq,
                            "frame_by_frame_fps": 1e3 / ms_seq, "render_frames_ms": ms_pipe, "render_frames_fps": 1e3 / ms_pipe,
                            "mpix_per_s": H * W / (ms_pipe * 1e-3) / 1e6}
+    # -- the reference's OWN call sequence through the drop-in interface (scripts/train.py:463,502,505-508): build_sigma_from_params +
+    #    evaluate_sh + render, autograd through all three, every call waiting for its frame's counters like the reference's code would --
+    #    what a caller gets who only switched the import
+    try:
+        gimg3 = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(1)).to(dev)
+        eye3 = torch.eye(4, device=dev)
+
+        def three_call():
+            for p in params.values():
+                p.grad = None
+            sigma = gs.build_sigma_from_params(params["scale_raw"], params["q_raw"])
+            color = gs.evaluate_sh(params["f_dc"], params["f_rest"], params["pos"], eye3)
+            gs.render(params["pos"], color, params["opacity_raw"], sigma, eye3, *cam_args).backward(gimg3)
+        if all(p.requires_grad for p in params.values()):
+            for _ in range(3):
+                three_call()
+            ms3 = timed(three_call, 20, fence)
+            out["three_call_sequence"] = {"workload": "config 3, forward + backward through gaussian_splatting's own three calls "
+                                                      "(build_sigma_from_params, evaluate_sh, render), each waiting for the frame's counters",
+                                          "ms_per_step": ms3, "mpix_per_s": H * W / (ms3 * 1e-3) / 1e6}
+        for p in params.values():
+            p.grad = None
+    except Exception as e:
+        out["three_call_sequence"] = {"error": f"{type(e).__name__}: {e}"}
     # -- one training iteration (scripts/train.py:446-569): render + L1/SSIM loss + backward + clip + Adam, one view
     model_mod = importlib.import_module(PKG + ".model")
     training = importlib.import_module(PKG + ".training")
