@@ -130,7 +130,7 @@ ProjectState carve_project(void* base, int64_t n, int64_t nl) {
     s.order = (uint32_t*)(p + o); o += up(nl * 4);
     s.class_bounds = (uint32_t*)(p + o); o += up(8 * 4);
     s.kj = (float*)(p + o); o += up(n * 48);
-    s.big_flag = (uint32_t*)(p + o); o += up(((n + 255) / 256 * 4) * 4);      // (padded to whole ranges of 256 Gaussians: 16-byte reads)
+    s.big_flag = (uint32_t*)(p + o); o += up(((n + 255) / 256 * 4) * 4);      // (one word per projection wave = range of 64 Gaussians)
     s.bytes = o;
     return s;
 }
@@ -317,9 +317,11 @@ __device__ __forceinline__ void for_each_list(u2 rect, uint32_t nt, uint32_t mas
 // The lists of the LARGE Gaussians held by the lanes of one wave (`big`: rectangle of more than 32 lists and binned at all), one
 // Gaussian after the other, the lanes taking the ROWS of its rectangle: f(first list of the row's span, lists in the span, payload)
 // per non-empty row (gs_math.h big_row_span: the same spans the projection kernel counted into tiles[]).  Call with all 64 lanes.
+// `mine`: which lanes' Gaussians this wave takes (the four waves of a big block hold the same 64 and take every fourth each).
 template <class F>
-__device__ __forceinline__ void for_each_big_row(bool big, u2 rect, f4 uvexy, f4 k4, uint64_t payload, int lists_x, int lane, F f) {
-    unsigned long long m = __ballot(big);
+__device__ __forceinline__ void for_each_big_row(bool big, u2 rect, f4 uvexy, f4 k4, uint64_t payload, int lists_x, int lane, F f,
+                                                 unsigned long long mine = ~0ull) {
+    unsigned long long m = __ballot(big) & mine;
     while (m) {
         const int src = __ffsll((long long)m) - 1;
         m &= m - 1;
@@ -584,16 +586,14 @@ __device__ __forceinline__ void for_block_pairs(const BlockPairs& bp, int lists_
     for (int k = 0; k < BlockPairs::K; ++k) for_each_list(bp.r[k], bp.nt[k], bp.mk[k], lists_x, lane, bp.payload[k], 0u, f);
 }
 
-// What a big block (256 Gaussians, see bin_count_kernel) holds per thread.  Returns false (uniformly) when the block's range has no
+// What a big block (a range of 64 Gaussians held by each of its four waves, see bin_count_kernel) holds per thread.  Returns false (uniformly) when the block's range has no
 // large Gaussian: the block then leaves -- at config 3 (none at all) that is all these blocks ever do.
 struct BigLane { bool big; u2 rect; f4 uvexy, k4; uint64_t payload; };      // centre + extents, row-span constants (record)
 __device__ __forceinline__ bool load_big_lane(int64_t i, int64_t n, const u2* __restrict__ rect, const uint32_t* __restrict__ tiles,
                                               const Rec64* __restrict__ rec, const float* __restrict__ depth, BigLane& b,
                                               const uint32_t* __restrict__ big_flag) {
-    {   // the four projection waves of this range (one uniform 16-byte load): nothing large -> nothing else is even loaded
-        const uint4 f = *reinterpret_cast<const uint4*>(big_flag + (i - threadIdx.x) / 64);
-        if (!(f.x | f.y | f.z | f.w)) return false;
-    }
+    // the projection wave of this range (one uniform load): nothing large -> nothing else is even loaded
+    if (!big_flag[(i - (threadIdx.x & 63)) / 64]) return false;
     b.rect = u2{0u, 0u};
     b.big = false;
     if (i < n) {
@@ -614,15 +614,25 @@ __device__ __forceinline__ bool load_big_lane(int64_t i, int64_t n, const u2* __
     return true;
 }
 
-// Does ANY of the ranges this big block will visit (first, first + stride, ...) hold a large Gaussian?  Thread t looks at the t-th of
-// them: one round trip for up to 256 ranges, and a block with nothing to do -- every one of them at config 3 -- leaves after it.
-__device__ __forceinline__ bool any_big_range(const uint32_t* __restrict__ big_flag, int64_t first, int64_t stride, int64_t ranges) {
-    bool has = false;
-    for (int64_t r = first + (int64_t)threadIdx.x * stride; r < ranges; r += 256 * stride) {
-        const uint4 f = *reinterpret_cast<const uint4*>(big_flag + r * 4);
-        has |= (f.x | f.y | f.z | f.w) != 0u;
+// body(range) for every range of this big block (first, first + stride, ...) whose projection wave flagged a large Gaussian.  The
+// flags are read in rounds of 256 candidate ranges, one per thread (one round trip per round), and the flagged ones listed in LDS:
+// a block with nothing to do -- every one of them at config 3 -- leaves after one round trip, and a scene with FEW large Gaussians
+// (config 5: 156 K ranges, 200 per block) does not probe its ranges one dependent load after the other.  body may synchronise the
+// workgroup (it is called uniformly).
+struct FlaggedLds { uint32_t list[256]; uint32_t count; };
+template <class Body>
+__device__ __forceinline__ void for_flagged_ranges(const uint32_t* __restrict__ big_flag, int64_t first, int64_t stride, int64_t ranges,
+                                                   FlaggedLds& fl, Body body) {
+    for (int64_t base = first; base < ranges; base += 256 * stride) {
+        if (threadIdx.x == 0) fl.count = 0u;
+        __syncthreads();
+        const int64_t r = base + (int64_t)threadIdx.x * stride;
+        if (r < ranges && big_flag[r] != 0u) fl.list[atomicAdd(&fl.count, 1u)] = (uint32_t)r;
+        __syncthreads();
+        const uint32_t cnt = fl.count;
+        for (uint32_t i = 0; i < cnt; ++i) body((int64_t)fl.list[i]);
+        __syncthreads();
     }
-    return __syncthreads_or(has);
 }
 
 // pieces of a run of consecutive lists [l0, l0 + cnt) by coarse bin: g(bin, first list of the piece, lists in the piece)
@@ -639,36 +649,44 @@ __device__ __forceinline__ void bin_count_big(int64_t n, const u2* __restrict__ 
                                                         uint32_t* __restrict__ bin_total, const Rec64* __restrict__ rec,
                                                         const uint32_t* __restrict__ big_flag, uint32_t small_blocks, uint32_t* hist) {
     const int tid = threadIdx.x;
-    const int64_t ranges = (n + 255) / 256;
-    if (!any_big_range(big_flag, blockIdx.x - small_blocks, gridDim.x - small_blocks, ranges)) return;
-    for (int64_t range = blockIdx.x - small_blocks; range < ranges; range += gridDim.x - small_blocks) {
+    const int64_t ranges = (n + 63) / 64;
+    const unsigned long long mine = 0x1111111111111111ull << (tid >> 6);          // this wave's quarter of the range's Gaussians
+    // the block's ranges are counted into ONE histogram, flushed once (a flush per range of 64: 123 K atomics on the 79 totals of
+    // config 6, +14 us)
+    __shared__ FlaggedLds fl;
+    bool any = false;
+    for (int b = tid; b < nb; b += 256) hist[b] = 0u;
+    for_flagged_ranges(big_flag, blockIdx.x - small_blocks, gridDim.x - small_blocks, ranges, fl, [&](int64_t range) {
         BigLane bl;
-        if (!load_big_lane(range * 256 + tid, n, rect, tiles, rec, nullptr, bl, big_flag)) continue;
-        for (int b = tid; b < nb; b += 256) hist[b] = 0u;
-        __syncthreads();
+        if (!load_big_lane(range * 64 + (tid & 63), n, rect, tiles, rec, nullptr, bl, big_flag)) return;
+        any = true;
         for_each_big_row(bl.big, bl.rect, bl.uvexy, bl.k4, 0ull, lists_x, tid & 63, [&](uint32_t l0, uint32_t cnt, uint64_t) {
             for_bin_pieces(l0, cnt, [&](uint32_t b, uint32_t, uint32_t c) { atomicAdd(&hist[b], c); });
-        });
-        __syncthreads();
-        for (int b = tid; b < nb; b += 256) {
-            const uint32_t c = hist[b];
-            if (c) atomicAdd(&bin_total[nb + b], c);           // (no offset is drawn here: bin_scatter_kernel's big blocks draw theirs)
-        }
-        __syncthreads();                                       // hist is cleared again by the next range
+        }, mine);
+    });
+    if (!any) return;                                      // (uniform; for_flagged_ranges ends with a barrier)
+    for (int b = tid; b < nb; b += 256) {
+        const uint32_t c = hist[b];
+        if (c) atomicAdd(&bin_total[nb + b], c);           // (no offset is drawn here: bin_scatter_kernel's big blocks draw theirs)
     }
 }
 
 // Grid = the blocks of 2048 Gaussians, which bin the SMALL Gaussians (rectangles of up to 32 lists, each lane walking its own), then
-// `big_blocks` blocks of 256 Gaussians, which bin the LARGE ones wave-cooperatively (for_each_big_row): a Gaussian of a trained
-// scene covers hundreds of lists, and 2048 of them per block left the chip with 49 workgroups walking half a million lists each.
+// `big_blocks` blocks, which bin the LARGE ones of ranges of 64 Gaussians wave-cooperatively (for_each_big_row; every wave of the block
+// holds the range's 64 Gaussians and takes every fourth): a Gaussian of a trained scene covers hundreds of lists, and 2048 of them per
+// block left the chip with 49 workgroups walking half a million lists each.  (Ranges of 256 with 64 Gaussians per wave, one after the
+// other, the first version: 1.5 waves per SIMD in a chain of dependent LDS atomics and shuffles -- 161 us for the scatter at config 6.)
 __global__ __launch_bounds__(256) void bin_count_kernel(int64_t n, const u2* __restrict__ rect, const uint32_t* __restrict__ tiles,
                                                         const uint32_t* __restrict__ mask, int lists_x, int nb, uint32_t* __restrict__ bin_total,
                                                         uint32_t* __restrict__ block_off, uint32_t* __restrict__ list_count,
                                                         uint2* __restrict__ ranges, int nl, CounterBlock* cb, DevCounts* counts,
                                                         DevCounts* counts_mapped, const Rec64* __restrict__ rec, const uint32_t* __restrict__ big_flag, uint32_t small_blocks) {
-    __shared__ uint32_t hist[MAX_BINS];
+    // hist[nb]: dynamic LDS, sized by the launch (a static array for the largest image, 32 KB, held the two binning kernels at 3-4
+    // workgroups per CU whatever the image: the blocks of the large Gaussians ran in three rounds)
+    extern __shared__ uint32_t bin_lds[];
+    uint32_t* const hist = bin_lds;
     const int tid = threadIdx.x;
-    if (blockIdx.x >= small_blocks) {            // ---- ranges of 256 Gaussians (grid-stride): the large ones of each range
+    if (blockIdx.x >= small_blocks) {            // ---- ranges of 64 Gaussians (grid-stride): the large ones of each range
         bin_count_big(n, rect, tiles, lists_x, nb, bin_total, rec, big_flag, small_blocks, hist);
         return;
     }
@@ -733,10 +751,16 @@ __global__ __launch_bounds__(256) void bin_count_kernel(int64_t n, const u2* __r
 // coarse-bin boundaries (a span of up to 33 lists crosses at most one: two rounds), each piece draws a run of slots from its bin's
 // cursor in LDS -- and then the PAIRS, not the rows, are dealt to the lanes (`owner`: which lane's piece pair k belongs to), so that a
 // store instruction writes up to 64 consecutive payloads instead of one 8-byte word into each of ~20 different runs.
+// GSPLAT_BIG_DIRECT=1: every lane writes its own row's run instead (no owner array, no shuffles; 8-byte stores into ~20 runs per
+// instruction).  Config 6: 105 against 131 us while the kernel sat at 3 workgroups per CU, 112 against 108 at 8 (the dynamic histogram
+// below); config 5, whose scatter is bound by half-written lines: +15 us.  Off.
+#ifndef GSPLAT_BIG_DIRECT
+#define GSPLAT_BIG_DIRECT 0
+#endif
 constexpr int BIG_ROUND_PAIRS = 64 * 34;             // 64 rows x the widest span a rectangle can have (radius <= 250 px: 33 lists)
 __device__ __forceinline__ void scatter_big_rows(const BigLane& bl, int lists_x, int lane, uint32_t* cur, uint8_t* owner, uint32_t n_binned,
-                                                 uint64_t* __restrict__ bvals) {
-    unsigned long long m = __ballot(bl.big);
+                                                 uint64_t* __restrict__ bvals, unsigned long long mine) {
+    unsigned long long m = __ballot(bl.big) & mine;
     while (m) {
         const int src = __ffsll((long long)m) - 1;
         m &= m - 1;
@@ -761,6 +785,16 @@ __device__ __forceinline__ void scatter_big_rows(const BigLane& bl, int lists_x,
                 const uint32_t c = !has ? 0u : (round == 0 ? min(l1 + 1u, cut) - l0 : (l1 >= cut ? l1 + 1u - cut : 0u));
                 if (!__any(c != 0u)) continue;
                 const uint32_t pos = c ? atomicAdd(&cur[a >> BIN_SHIFT], c) : 0u;
+#if GSPLAT_BIG_DIRECT
+                // every lane writes its own row's run: 8-byte stores into ~20 different runs per instruction, consecutive instructions
+                // filling the same lines (the L2 merges them)
+                for (uint32_t j = 0; j < c; ++j) {
+                    const uint32_t dst = pos + j, l = a + j;
+                    if (dst < n_binned) bvals[dst] = pl | ((uint64_t)(l & ((1u << BIN_SHIFT) - 1u)) << ID_BITS);
+                }
+                (void)owner;
+                continue;
+#endif
                 uint32_t incl = c;
                 for (int d = 1; d < 64; d <<= 1) {
                     const uint32_t up_ = (uint32_t)__shfl_up((int)incl, d);
@@ -768,9 +802,9 @@ __device__ __forceinline__ void scatter_big_rows(const BigLane& bl, int lists_x,
                 }
                 const uint32_t pre = incl - c, total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                 for (uint32_t j = 0; j < c; ++j) owner[pre + j] = (uint8_t)lane;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
                 __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
                 for (uint32_t k0 = 0; k0 < total; k0 += 64) {                   // (uniform trip count: a shuffle reads nothing from a lane that
                     const uint32_t k = k0 + (uint32_t)lane;                     //  has left the loop)
                     const int o = k < total ? owner[k] : 0;
@@ -778,9 +812,9 @@ __device__ __forceinline__ void scatter_big_rows(const BigLane& bl, int lists_x,
                     const uint32_t dst = (uint32_t)__shfl((int)pos, o) + j, l = (uint32_t)__shfl((int)a, o) + j;
                     if (k < total && dst < n_binned) bvals[dst] = pl | ((uint64_t)(l & ((1u << BIN_SHIFT) - 1u)) << ID_BITS);
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
                 __builtin_amdgcn_wave_barrier();                                // `owner` is rewritten by the next round
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
             }
         }
     }
@@ -793,7 +827,7 @@ __device__ __forceinline__ void scatter_big_rows(const BigLane& bl, int lists_x,
 // Exclusive prefix of the bin totals (small + large) for both kinds of block: thread t owns a contiguous run of ceil(nb / 256) bins and
 // calls own(b, start of bin b, total of bin b, k) for each of them (k = index inside the run; the first four totals are in bt[]).
 // The first four of a thread's totals are loaded up front (all of them up to 1024 bins = 4 M pixels): one round trip, not three.
-struct BinPrefix { int per, first; uint32_t bt[4], run; };
+struct BinPrefix { int per, first; uint32_t bt[4], small[4], run; };      // bt = small + large pairs of the bin, small = the small Gaussians' part
 __device__ __forceinline__ BinPrefix bin_prefix_load(const uint32_t* __restrict__ bin_total, int nb) {
     BinPrefix p;
     p.per = (nb + 255) / 256;
@@ -801,7 +835,8 @@ __device__ __forceinline__ BinPrefix bin_prefix_load(const uint32_t* __restrict_
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const bool in = k < p.per && p.first + k < nb;
-        p.bt[k] = in ? bin_total[p.first + k] + bin_total[nb + p.first + k] : 0u;
+        p.small[k] = in ? bin_total[p.first + k] : 0u;
+        p.bt[k] = p.small[k] + (in ? bin_total[nb + p.first + k] : 0u);
     }
     p.run = p.bt[0] + p.bt[1] + p.bt[2] + p.bt[3];
     for (int k = 4; k < p.per; ++k) p.run += p.first + k < nb ? bin_total[p.first + k] + bin_total[nb + p.first + k] : 0u;
@@ -828,32 +863,46 @@ __device__ __forceinline__ void bin_scatter_big(int64_t n, const u2* __restrict_
                                                           const uint32_t* __restrict__ big_flag, uint32_t small_blocks, uint32_t* cur, uint32_t* wsum,
                                                           uint8_t* owner) {
     const int tid = threadIdx.x, lane = tid & 63;
-    const int64_t ranges = (n + 255) / 256;
-    if (!any_big_range(big_flag, blockIdx.x - small_blocks, gridDim.x - small_blocks, ranges)) return;
-    for (int64_t range = blockIdx.x - small_blocks; range < ranges; range += gridDim.x - small_blocks) {
+    const int64_t ranges = (n + 63) / 64;
+    const unsigned long long mine = 0x1111111111111111ull << (tid >> 6);          // this wave's quarter of the range's Gaussians
+    __shared__ FlaggedLds fl;
+    for_flagged_ranges(big_flag, blockIdx.x - small_blocks, gridDim.x - small_blocks, ranges, fl, [&](int64_t range) {
         BigLane bl;
-        if (!load_big_lane(range * 256 + tid, n, rect, tiles, rec, depth, bl, big_flag)) continue;
+        if (!load_big_lane(range * 64 + lane, n, rect, tiles, rec, depth, bl, big_flag)) return;
         const BinPrefix bpf = bin_prefix_load(bin_total, nb);
         for (int b = tid; b < nb; b += 256) cur[b] = 0u;
         __syncthreads();
         for_each_big_row(bl.big, bl.rect, bl.uvexy, bl.k4, 0ull, lists_x, lane, [&](uint32_t l0, uint32_t cnt, uint64_t) {
             for_bin_pieces(l0, cnt, [&](uint32_t b, uint32_t, uint32_t c) { atomicAdd(&cur[b], c); });      // this range's pairs per bin
-        });
+        }, mine);
         uint32_t st = bin_prefix_scan(bpf, wsum);              // (its barrier also closes the counting)
-        for (int k = 0; k < bpf.per; ++k) {
+        // start of the bin + its small part + what this block draws from the large part's cursor (ONE returning atomic per touched
+        // bin and block; the atomics of a thread's first four bins are in flight together: a range pays one round trip for them,
+        // not one per bin)
+        uint32_t mine4[4], got4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mine4[k] = (k < bpf.per && bpf.first + k < nb) ? cur[bpf.first + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) got4[k] = mine4[k] ? atomicAdd(&bin_total[2 * nb + bpf.first + k], mine4[k]) : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < bpf.per && bpf.first + k < nb) {
+                if (mine4[k]) cur[bpf.first + k] = st + bpf.small[k] + got4[k];
+                st += bpf.bt[k];
+            }
+        }
+        for (int k = 4; k < bpf.per; ++k) {                    // (more than 1024 bins: images beyond 4 M pixels)
             const int b = bpf.first + k;
             if (b < nb) {
-                // start of the bin + its small part + what this block draws from the large part's cursor (ONE returning atomic per
-                // touched bin and block)
                 const uint32_t mine = cur[b];
                 if (mine) cur[b] = st + bin_total[b] + atomicAdd(&bin_total[2 * nb + b], mine);
-                st += k < 4 ? bpf.bt[k & 3] : bin_total[b] + bin_total[nb + b];
+                st += bin_total[b] + bin_total[nb + b];
             }
         }
         __syncthreads();
-        scatter_big_rows(bl, lists_x, lane, cur, owner, n_binned, bvals);
+        scatter_big_rows(bl, lists_x, lane, cur, owner, n_binned, bvals, mine);
         __syncthreads();                                        // cur is cleared again by the next range
-    }
+    });
 }
 
 __global__ __launch_bounds__(256) void bin_scatter_kernel(int64_t n, const u2* __restrict__ rect, const uint32_t* __restrict__ tiles,
@@ -862,10 +911,12 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(int64_t n, const u2* _
                                                           uint32_t* __restrict__ bin_start, uint32_t n_binned,
                                                           uint64_t* __restrict__ bvals, const Rec64* __restrict__ rec,
                                                           const uint32_t* __restrict__ big_flag, uint32_t small_blocks) {
-    __shared__ uint32_t cur[MAX_BINS], wsum[4];
+    extern __shared__ uint32_t bin_lds[];                  // cur[nb] (see bin_count_kernel)
+    uint32_t* const cur = bin_lds;
+    __shared__ uint32_t wsum[4];
     __shared__ uint8_t owner[4][BIG_ROUND_PAIRS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (blockIdx.x >= small_blocks) {            // ---- ranges of 256 Gaussians (grid-stride): the large ones of each range
+    if (blockIdx.x >= small_blocks) {            // ---- ranges of 64 Gaussians (grid-stride): the large ones of each range
         bin_scatter_big(n, rect, tiles, depth, lists_x, nb, bin_total, n_binned, bvals, rec, big_flag, small_blocks, cur, wsum, owner[wave]);
         return;
     }
@@ -1106,13 +1157,15 @@ __global__ __launch_bounds__(SS_THREADS) void split_scatter_kernel(int nl, int n
 // +inf padding above n no real element is ever exchanged with the padding, so the network also runs in place.
 // Synchronisation of the threads that sort one list: the workgroup, or -- when a wave sorts a list by itself inside a larger
 // workgroup -- nothing but the order of the wave's own LDS instructions (the LDS executes one wave's instructions in issue
-// order; the fences keep the compiler from moving accesses across).
+// order; the fences keep the compiler from moving accesses across).  The fences name the LDS ("local"): a plain wavefront-scope
+// release also waits for the wave's outstanding GLOBAL stores (s_waitcnt vmcnt(0)) -- the large Gaussians' scatter stood 2 us per
+// round on that, the wave-per-list sort once per list.
 template <bool WAVE>
 __device__ __forceinline__ void group_sync() {
     if (WAVE) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     } else {
         __syncthreads();
     }
@@ -2302,12 +2355,29 @@ __global__ __launch_bounds__(64) void evaluate_sh_backward_kernel(int64_t n, con
 }
 
 inline unsigned blocks256(int64_t n) { return (unsigned)((n + 255) / 256); }
-// workgroups of the binning kernels that look for LARGE Gaussians (ranges of 256, grid-stride): enough to fill the chip when every
-// Gaussian is large, few enough to cost a scene without any (config 3: 3906 ranges) almost nothing
-#ifndef GSPLAT_BIG_BLOCKS_MAX
-#define GSPLAT_BIG_BLOCKS_MAX 512u
+// Dynamic LDS of the two binning kernels: nb counters -- padded so that only `per_cu` of their workgroups fit a CU when the image has
+// many bins.  Every resident block of bin_scatter_kernel keeps one open line per bin it writes to; with 8 blocks per CU and the 1012
+// bins of a 4K image that is 2 M lines under 32 MB of L2: lines leave half written and come back (config 5: 202 us at 3 blocks per
+// CU, 285 at 8); a small image has few bins and wants the occupancy (config 6: 131 us at 3, 108 at 8).
+inline size_t bin_lds_bytes(size_t nb, size_t static_bytes, size_t least = 2) {
+    size_t per_cu = 2048 / (nb ? nb : 1);
+#ifdef GSPLAT_BIN_PER_CU
+    per_cu = GSPLAT_BIN_PER_CU;
 #endif
-inline unsigned big_bin_blocks(int64_t n) { return std::min(blocks256(n), GSPLAT_BIG_BLOCKS_MAX); }
+    if (per_cu < least) per_cu = least;
+    if (per_cu >= 8) return nb * 4;
+    const size_t want = (160 * 1024) / (per_cu + 1) + 1024;          // one more block must not fit
+    const size_t dyn = want > static_bytes ? want - static_bytes : 0;
+    return std::min(std::max(nb * 4, dyn), (size_t)(64 * 1024 - 256));
+}
+// workgroups of the binning kernels that look for LARGE Gaussians (ranges of 64, grid-stride): enough to fill the chip when every
+// Gaussian is large, few enough to cost a scene without any (config 3: 15 625 ranges, one flag word each) almost nothing
+#ifndef GSPLAT_BIG_BLOCKS_MAX
+#define GSPLAT_BIG_BLOCKS_MAX 2048u
+#endif
+inline unsigned big_bin_blocks(int64_t n) { return std::min((unsigned)((n + 63) / 64), GSPLAT_BIG_BLOCKS_MAX); }
+// (bin_count_kernel: fewer, each adding its ranges up before it touches the global totals)
+inline unsigned big_count_blocks(int64_t n) { return std::min((unsigned)((n + 63) / 64), 768u); }
 inline unsigned blocks64(int64_t n) { return (unsigned)((n + 63) / 64); }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -2411,7 +2481,7 @@ int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_vie
     }
     if (counts_event && !late) HIP_TRY(hipEventRecord((hipEvent_t)counts_event, st));
     if (n > 0) {                    // these need no pair buffer: queued behind the event, they run while a waiting host sizes the buffers
-        hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)(n_bin_blocks(n) + big_bin_blocks(n))), dim3(256), 0, st, n, ps.rect, ps.tiles, ps.mask, vk.lists_x, (int)nb,
+        hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)(n_bin_blocks(n) + big_count_blocks(n))), dim3(256), bin_lds_bytes(nb, 256, 4), st, n, ps.rect, ps.tiles, ps.mask, vk.lists_x, (int)nb,
                            ps.bin_total, ps.block_off, ps.list_count, ps.ranges, (int)nl, late ? (CounterBlock*)scratch : nullptr, ps.counts,
                            late && mapped ? (DevCounts*)counts_host : nullptr, ps.rec, ps.big_flag, (uint32_t)n_bin_blocks(n));
         LAUNCH_CHECK("bin_count_kernel");
@@ -2448,7 +2518,7 @@ int gsplat_bin(int64_t n, int64_t pair_capacity, const gsplat_view* v, const voi
     BinScratch sc = carve_bin_scratch(scratch, n_binned, nb);
     if (!scratch || sc.bytes > scratch_bytes) return fail(GSPLAT_ERR_WORKSPACE, "bin scratch too small");
     uint32_t* sorted_ids = (uint32_t*)bin_state;
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3((unsigned)(n_bin_blocks(n) + big_bin_blocks(n))), dim3(256), 0, st, n, ps.rect, ps.tiles, ps.mask, ps.depth, vk.lists_x,
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3((unsigned)(n_bin_blocks(n) + big_bin_blocks(n))), dim3(256), bin_lds_bytes(nb, 9 * 1024), st, n, ps.rect, ps.tiles, ps.mask, ps.depth, vk.lists_x,
                        (int)nb, ps.bin_total, ps.block_off, ps.bin_start, (uint32_t)n_binned, sc.bvals, ps.rec, ps.big_flag,
                        (uint32_t)n_bin_blocks(n));
     LAUNCH_CHECK("bin_scatter_kernel");
