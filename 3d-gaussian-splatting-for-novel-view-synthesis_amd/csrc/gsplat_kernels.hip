@@ -340,6 +340,40 @@ __device__ __forceinline__ void for_each_big_row(bool big, u2 rect, f4 uvexy, f4
     }
 }
 
+// Inclusive prefix sum over the 64 lanes in the VALU (DPP row shifts inside the rows of 16, row broadcasts across them): six adds,
+// where six __shfl_up are six round trips through the LDS crossbar.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x) {
+#define DPP_U32(v, ctrl, rmask) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rmask, 0xF, false)
+    x += DPP_U32(x, 0x111, 0xF);            // row_shr:1
+    x += DPP_U32(x, 0x112, 0xF);            // row_shr:2
+    x += DPP_U32(x, 0x114, 0xF);            // row_shr:4
+    x += DPP_U32(x, 0x118, 0xF);            // row_shr:8
+    x += DPP_U32(x, 0x142, 0xA);            // row_bcast:15 -> rows 1, 3
+    x += DPP_U32(x, 0x143, 0xC);            // row_bcast:31 -> rows 2, 3
+#undef DPP_U32
+    return x;
+}
+
+// Sum / maximum / minimum over the 64 lanes the same way (the result in every lane, through lane 63 and an SGPR): six DPP steps
+// instead of six ds_bpermute butterflies.
+#define GS_DPP_U32(v, idn, ctrl, rmask) (uint32_t)__builtin_amdgcn_update_dpp((int)(idn), (int)(v), ctrl, rmask, 0xF, false)
+__device__ __forceinline__ uint32_t wave_sum(uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(x), 63);
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t x) {
+    x = max(x, GS_DPP_U32(x, 0u, 0x111, 0xF)); x = max(x, GS_DPP_U32(x, 0u, 0x112, 0xF));
+    x = max(x, GS_DPP_U32(x, 0u, 0x114, 0xF)); x = max(x, GS_DPP_U32(x, 0u, 0x118, 0xF));
+    x = max(x, GS_DPP_U32(x, 0u, 0x142, 0xA)); x = max(x, GS_DPP_U32(x, 0u, 0x143, 0xC));
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+__device__ __forceinline__ uint32_t wave_min(uint32_t x) {
+    x = min(x, GS_DPP_U32(x, 0xFFFFFFFFu, 0x111, 0xF)); x = min(x, GS_DPP_U32(x, 0xFFFFFFFFu, 0x112, 0xF));
+    x = min(x, GS_DPP_U32(x, 0xFFFFFFFFu, 0x114, 0xF)); x = min(x, GS_DPP_U32(x, 0xFFFFFFFFu, 0x118, 0xF));
+    x = min(x, GS_DPP_U32(x, 0xFFFFFFFFu, 0x142, 0xA)); x = min(x, GS_DPP_U32(x, 0xFFFFFFFFu, 0x143, 0xC));
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+#undef GS_DPP_U32
+
 // COLOUR = false (fused inputs): geometry only, 44 of the 236 input bytes; colour_kernel evaluates the SH colour later,
 // queued behind the copy of the counters so that it runs while the host reads them and sizes the binning buffers.
 // The camera block (w2c, eye) is derived from c2w by every wave itself (16 uniform loads + 30 flops: cheaper than the launch of
@@ -440,12 +474,7 @@ __global__ __launch_bounds__(64) void project_kernel(gsplat_gaussians g, const f
     }
     const unsigned long long surv = __ballot(o.vis != VIS_CULLED);
     const unsigned long long seen = __ballot(o.vis == VIS_OK);
-    uint32_t mx = r.tiles, refp = r.ref_tiles, binp = r.tiles;
-    for (int sft = 32; sft > 0; sft >>= 1) {
-        mx = max(mx, (uint32_t)__shfl_xor((int)mx, sft));
-        refp += (uint32_t)__shfl_xor((int)refp, sft);
-        binp += (uint32_t)__shfl_xor((int)binp, sft);
-    }
+    const uint32_t mx = wave_max(r.tiles), refp = wave_sum(r.ref_tiles), binp = wave_sum(r.tiles);
     uint32_t arrived = 0u;
     if (lane == 0) {
         CountShard* sh = cb->shards + (blockIdx.x % COUNT_SHARDS);
@@ -795,11 +824,7 @@ __device__ __forceinline__ void scatter_big_rows(const BigLane& bl, int lists_x,
                 (void)owner;
                 continue;
 #endif
-                uint32_t incl = c;
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t up_ = (uint32_t)__shfl_up((int)incl, d);
-                    if (lane >= d) incl += up_;
-                }
+                const uint32_t incl = wave_inclusive_scan(c);
                 const uint32_t pre = incl - c, total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                 for (uint32_t j = 0; j < c; ++j) owner[pre + j] = (uint8_t)lane;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
@@ -845,11 +870,7 @@ __device__ __forceinline__ BinPrefix bin_prefix_load(const uint32_t* __restrict_
 // start of the thread's first bin (one workgroup barrier inside)
 __device__ __forceinline__ uint32_t bin_prefix_scan(const BinPrefix& p, uint32_t* wsum) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = p.run;
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up_ = (uint32_t)__shfl_up((int)incl, d);
-        if (lane >= d) incl += up_;
-    }
+    const uint32_t incl = wave_inclusive_scan(p.run);
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
     uint32_t st = incl - p.run;
@@ -1048,11 +1069,7 @@ __device__ __forceinline__ void plan_body(int nl, Len len, uint32_t* __restrict_
     uint32_t c[CPT], run = 0u;
 #pragma unroll
     for (int k = 0; k < CPT; ++k) { c[k] = cnt[tid * CPT + k]; run += c[k]; }
-    uint32_t incl = run;
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up_ = (uint32_t)__shfl_up((int)incl, d);
-        if (lane >= d) incl += up_;
-    }
+    const uint32_t incl = wave_inclusive_scan(run);
     if (lane == 63) wsum[wave] = incl;
     __syncthreads();
     uint32_t st = incl - run;
@@ -1120,11 +1137,7 @@ __global__ __launch_bounds__(SS_THREADS) void split_scatter_kernel(int nl, int n
         for (int u = 0; u < U; ++u) v[u] = s + u * SS_THREADS + tid < e ? bvals[s + u * SS_THREADS + tid] : ~0ull;
         if (tid < L) {                                          // one wave: exclusive scan of the bin's 64 list sizes
             const uint32_t c = list_count[b * L + tid];
-            uint32_t incl = c;
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t up_ = (uint32_t)__shfl_up((int)incl, d);
-                if (tid >= d) incl += up_;
-            }
+            const uint32_t incl = wave_inclusive_scan(c);
             const uint32_t st = bs + incl - c;
             cur[tid] = st + seg_off[((int64_t)chunk + b) * L + tid];           // garbage where the segment has no pair: unused
             const int list = b * L + tid;
@@ -1244,10 +1257,8 @@ __device__ __forceinline__ void sort_list(SortLds<T, E, LOG2B>& s, int tid, uint
     }
     for (int c = tid; c < B + T; c += T) cnt[c] = 0u;
     if (tid == 0) { red[0] = 0xFFFFFFFFu; red[1] = 0u; red[2] = 0u; }
-    for (int sft = 32; sft > 0; sft >>= 1) {
-        mn = min(mn, (uint32_t)__shfl_xor((int)mn, sft));
-        mx = max(mx, (uint32_t)__shfl_xor((int)mx, sft));
-    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
     group_sync<WAVE>();
     if ((tid & 63) == 0) { atomicMin(&red[0], mn); atomicMax(&red[1], mx); }
     group_sync<WAVE>();
@@ -1271,12 +1282,8 @@ __device__ __forceinline__ void sort_list(SortLds<T, E, LOG2B>& s, int tid, uint
         run += v;
         big = max(big, v);
     }
-    uint32_t incl = run;
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up_ = (uint32_t)__shfl_up((int)incl, d);
-        if ((tid & 63) >= d) incl += up_;
-    }
-    for (int sft = 32; sft > 0; sft >>= 1) big = max(big, (uint32_t)__shfl_xor((int)big, sft));
+    const uint32_t incl = wave_inclusive_scan(run);
+    big = wave_max(big);
     if ((tid & 63) == 63) red[4 + (tid >> 6)] = incl;
     if ((tid & 63) == 0) atomicMax(&red[2], big);
     group_sync<WAVE>();
@@ -2055,11 +2062,7 @@ __global__ __launch_bounds__(256) void pair_base_kernel(int64_t n, const uint32_
     const int64_t i0 = (int64_t)blockIdx.x * PB_BLOCK + (int64_t)tid * K;
 #pragma unroll
     for (int k = 0; k < K; ++k) { v[k] = i0 + k < n ? tiles[i0 + k] : 0u; run += v[k]; }
-    uint32_t incl = run;
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up_ = (uint32_t)__shfl_up((int)incl, d);
-        if (lane >= d) incl += up_;
-    }
+    const uint32_t incl = wave_inclusive_scan(run);
     __syncthreads();
     if (lane == 63) ws[wave] = incl;
     __syncthreads();
