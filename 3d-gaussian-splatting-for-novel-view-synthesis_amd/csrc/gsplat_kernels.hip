@@ -108,7 +108,11 @@ struct ProjectState {
 
 inline int64_t n_lists(const gsplat_view* v) { return (int64_t)((v->W + LIST_W - 1) / LIST_W) * ((v->H + LIST_H - 1) / LIST_H); }
 inline int64_t n_bins(int64_t nl) { return (nl + (1 << BIN_SHIFT) - 1) >> BIN_SHIFT; }
-inline int64_t n_bin_blocks(int64_t n) { return (n + BIN_GAUSS - 1) / BIN_GAUSS; }
+// A block of the two binning kernels takes `bin_batches(n)` batches of 2048 Gaussians, one after the other, into the same LDS
+// histogram / cursors: for a very large scene this keeps the number of blocks near a thousand -- each block pays one returning global
+// atomic per bin (config 5: 4883 blocks x 1012 bins = 4.9 M of them) and keeps one half-written line per bin open in the scatter.
+inline int bin_batches(int64_t n) { const int64_t b = n / ((int64_t)BIN_GAUSS * 1024); return (int)(b < 1 ? 1 : (b > 4 ? 4 : b)); }
+inline int64_t n_bin_blocks(int64_t n) { const int64_t per = (int64_t)BIN_GAUSS * bin_batches(n); return (n + per - 1) / per; }
 
 ProjectState carve_project(void* base, int64_t n, int64_t nl) {
     ProjectState s;
@@ -584,14 +588,14 @@ struct BlockPairs {                    // the 8 Gaussians of one thread of a bin
 // clearing LDS, barriers) between this and for_block_pairs.  The rectangle, mask and depth of a Gaussian that is not binned are
 // stale values: read and ignored.
 __device__ __forceinline__ BlockPairs load_block_pairs(int64_t n, const u2* __restrict__ rect, const uint32_t* __restrict__ tiles,
-                                                       const uint32_t* __restrict__ mask, const float* __restrict__ depth) {
+                                                       const uint32_t* __restrict__ mask, const float* __restrict__ depth, int64_t batch) {
     constexpr int K = BlockPairs::K;
     BlockPairs bp;
     float dz[K];
     const int tid = threadIdx.x;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const int64_t i = (int64_t)blockIdx.x * BIN_GAUSS + k * 256 + tid;
+        const int64_t i = batch * BIN_GAUSS + k * 256 + tid;
         const bool in = i < n;
         bp.nt[k] = in ? tiles[i] : 0u;
         bp.r[k] = in ? rect[i] : u2{0u, 0u};
@@ -602,7 +606,7 @@ __device__ __forceinline__ BlockPairs load_block_pairs(int64_t n, const u2* __re
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const int64_t i = (int64_t)blockIdx.x * BIN_GAUSS + k * 256 + tid;
+        const int64_t i = batch * BIN_GAUSS + k * 256 + tid;
         bp.payload[k] = ((uint64_t)f2u(dz[k]) << 32) | (uint64_t)(uint32_t)i;
     }
     return bp;
@@ -709,7 +713,8 @@ __global__ __launch_bounds__(256) void bin_count_kernel(int64_t n, const u2* __r
                                                         const uint32_t* __restrict__ mask, int lists_x, int nb, uint32_t* __restrict__ bin_total,
                                                         uint32_t* __restrict__ block_off, uint32_t* __restrict__ list_count,
                                                         uint2* __restrict__ ranges, int nl, CounterBlock* cb, DevCounts* counts,
-                                                        DevCounts* counts_mapped, const Rec64* __restrict__ rec, const uint32_t* __restrict__ big_flag, uint32_t small_blocks) {
+                                                        DevCounts* counts_mapped, const Rec64* __restrict__ rec, const uint32_t* __restrict__ big_flag, uint32_t small_blocks,
+                                                        int batches) {
     // hist[nb]: dynamic LDS, sized by the launch (a static array for the largest image, 32 KB, held the two binning kernels at 3-4
     // workgroups per CU whatever the image: the blocks of the large Gaussians ran in three rounds)
     extern __shared__ uint32_t bin_lds[];
@@ -719,7 +724,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(int64_t n, const u2* __r
         bin_count_big(n, rect, tiles, lists_x, nb, bin_total, rec, big_flag, small_blocks, hist);
         return;
     }
-    const BlockPairs bp = load_block_pairs(n, rect, tiles, mask, nullptr);
+    BlockPairs bp = load_block_pairs(n, rect, tiles, mask, nullptr, (int64_t)blockIdx.x * batches);
     if (cb && blockIdx.x == 0) {                 // GSPLAT_PROJECT_COUNTS_LATE: totals of the projection's sharded counters; shards cleared
         static_assert(COUNT_SHARDS == 256, "one shard per thread");
         __shared__ unsigned long long tsum[4][4];
@@ -765,7 +770,11 @@ __global__ __launch_bounds__(256) void bin_count_kernel(int64_t n, const u2* __r
     }
     for (int b = tid; b < nb; b += 256) hist[b] = 0u;
     __syncthreads();
-    for_block_pairs(bp, lists_x, [&](uint32_t l, uint32_t, uint64_t, uint32_t) { atomicAdd(&hist[l >> BIN_SHIFT], 1u); });
+    for (int bt = 0;;) {
+        for_block_pairs(bp, lists_x, [&](uint32_t l, uint32_t, uint64_t, uint32_t) { atomicAdd(&hist[l >> BIN_SHIFT], 1u); });
+        if (++bt >= batches) break;
+        bp = load_block_pairs(n, rect, tiles, mask, nullptr, (int64_t)blockIdx.x * batches + bt);
+    }
     __syncthreads();
     for (int b = tid; b < nb; b += 256) {
         const uint32_t c = hist[b];
@@ -931,7 +940,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(int64_t n, const u2* _
                                                           uint32_t* __restrict__ bin_total, const uint32_t* __restrict__ block_off,
                                                           uint32_t* __restrict__ bin_start, uint32_t n_binned,
                                                           uint64_t* __restrict__ bvals, const Rec64* __restrict__ rec,
-                                                          const uint32_t* __restrict__ big_flag, uint32_t small_blocks) {
+                                                          const uint32_t* __restrict__ big_flag, uint32_t small_blocks, int batches) {
     extern __shared__ uint32_t bin_lds[];                  // cur[nb] (see bin_count_kernel)
     uint32_t* const cur = bin_lds;
     __shared__ uint32_t wsum[4];
@@ -941,7 +950,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(int64_t n, const u2* _
         bin_scatter_big(n, rect, tiles, depth, lists_x, nb, bin_total, n_binned, bvals, rec, big_flag, small_blocks, cur, wsum, owner[wave]);
         return;
     }
-    const BlockPairs bp = load_block_pairs(n, rect, tiles, mask, depth);
+    BlockPairs bp = load_block_pairs(n, rect, tiles, mask, depth, (int64_t)blockIdx.x * batches);
     const BinPrefix bpf = bin_prefix_load(bin_total, nb);
     uint32_t bo[4];
 #pragma unroll
@@ -960,11 +969,15 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(int64_t n, const u2* _
         }
     }
     __syncthreads();
-    for_block_pairs(bp, lists_x, [&](uint32_t l, uint32_t, uint64_t pl, uint32_t) {
-        const uint32_t pos = atomicAdd(&cur[l >> BIN_SHIFT], 1u);
-        if (pos < n_binned)                                 // defensive: never write past the caller's buffer
-            bvals[pos] = pl | ((uint64_t)(l & ((1u << BIN_SHIFT) - 1u)) << ID_BITS);
-    });
+    for (int bt = 0;;) {
+        for_block_pairs(bp, lists_x, [&](uint32_t l, uint32_t, uint64_t pl, uint32_t) {
+            const uint32_t pos = atomicAdd(&cur[l >> BIN_SHIFT], 1u);
+            if (pos < n_binned)                             // defensive: never write past the caller's buffer
+                bvals[pos] = pl | ((uint64_t)(l & ((1u << BIN_SHIFT) - 1u)) << ID_BITS);
+        });
+        if (++bt >= batches) break;
+        bp = load_block_pairs(n, rect, tiles, mask, depth, (int64_t)blockIdx.x * batches + bt);
+    }
 }
 
 // split_count_kernel / split_scatter_kernel: every bin is split into its 64 lists.  Work is cut into chunks of 4096 pairs
@@ -2486,7 +2499,7 @@ int gsplat_project(const gsplat_gaussians* g, const float* c2w, const gsplat_vie
     if (n > 0) {                    // these need no pair buffer: queued behind the event, they run while a waiting host sizes the buffers
         hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)(n_bin_blocks(n) + big_count_blocks(n))), dim3(256), bin_lds_bytes(nb, 256, 4), st, n, ps.rect, ps.tiles, ps.mask, vk.lists_x, (int)nb,
                            ps.bin_total, ps.block_off, ps.list_count, ps.ranges, (int)nl, late ? (CounterBlock*)scratch : nullptr, ps.counts,
-                           late && mapped ? (DevCounts*)counts_host : nullptr, ps.rec, ps.big_flag, (uint32_t)n_bin_blocks(n));
+                           late && mapped ? (DevCounts*)counts_host : nullptr, ps.rec, ps.big_flag, (uint32_t)n_bin_blocks(n), bin_batches(n));
         LAUNCH_CHECK("bin_count_kernel");
         if (late) {                 // the counters exist only now
             if (counts_host && !mapped) HIP_TRY(hipMemcpyAsync(counts_host, ps.counts, sizeof(gsplat_counts), hipMemcpyDeviceToHost, st));
@@ -2523,7 +2536,7 @@ int gsplat_bin(int64_t n, int64_t pair_capacity, const gsplat_view* v, const voi
     uint32_t* sorted_ids = (uint32_t*)bin_state;
     hipLaunchKernelGGL(bin_scatter_kernel, dim3((unsigned)(n_bin_blocks(n) + big_bin_blocks(n))), dim3(256), bin_lds_bytes(nb, 9 * 1024), st, n, ps.rect, ps.tiles, ps.mask, ps.depth, vk.lists_x,
                        (int)nb, ps.bin_total, ps.block_off, ps.bin_start, (uint32_t)n_binned, sc.bvals, ps.rec, ps.big_flag,
-                       (uint32_t)n_bin_blocks(n));
+                       (uint32_t)n_bin_blocks(n), bin_batches(n));
     LAUNCH_CHECK("bin_scatter_kernel");
     hipLaunchKernelGGL(split_count_kernel, dim3((unsigned)n_chunks(n_binned)), dim3(256), 0, st, (int)nb, ps.bin_start, sc.bvals,
                        (uint32_t)n_binned, ps.counts, ps.list_count, sc.seg_off);
