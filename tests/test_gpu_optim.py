@@ -85,3 +85,44 @@ def test_full_training_step_runs():
         opt.step()
         hist.append(parts['total'])
     assert all(np.isfinite(hist)) and hist[-1] < 0.8 * hist[0], hist
+
+
+@pytest.mark.gpu
+def test_adam_launch_for_many_tensors_handles_tails_unaligned_views_and_more_than_eight_groups():
+    """gsplat_adam_step_multi: one launch for up to eight tensors with 16-byte accesses where the four arrays of a tensor allow it.
+    Sizes that are no multiple of four (the tail), views that start 4 bytes into an allocation (the scalar path), an empty tensor, and
+    eleven tensors (two launches) against torch.optim.Adam in float64; the second step runs with a clip coefficient on one tensor."""
+    optim = importlib.import_module(PKG + ".optim")
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(3)
+    sizes = [1, 2, 3, 5, 4097, 70001, 0, 1024, 333, 12, 7]
+    base, params, ref, first = [], [], [], {}
+    for k, n in enumerate(sizes):
+        off = 1 if k % 3 == 1 else 0                                       # every third tensor: misaligned by one float
+        buf = torch.randn(n + off, generator=g).to(dev)
+        base.append(buf)
+        first[k] = float(buf[0]) if n + off else None
+        p = buf[off:].detach().requires_grad_(True)
+        assert (p.data_ptr() % 16 != 0) == (off == 1 and n > 0) or n == 0
+        params.append(p)
+        ref.append(torch.nn.Parameter(p.detach().cpu().double()))
+    groups = [{'params': [p], 'lr': 0.01 * (k + 1)} for k, p in enumerate(params)]
+    opt = optim.GaussianAdam(groups, lr=0.01, eps=1e-15)
+    topt = torch.optim.Adam([{'params': [r], 'lr': 0.01 * (k + 1)} for k, r in enumerate(ref)], lr=0.01, eps=1e-15)
+    for step in range(3):
+        for p, r in zip(params, ref):
+            gr = torch.randn(p.shape, generator=g) * (5.0 if step == 1 else 1.0)
+            p.grad = gr.to(dev) if p.numel() else torch.zeros_like(p)
+            r.grad = gr.double()
+        if step == 1:
+            opt.clip_grad_norm_(params[5], max_norm=1.0)
+            torch.nn.utils.clip_grad_norm_(ref[5], max_norm=1.0)
+        opt.step()
+        topt.step()
+        for k, (p, r) in enumerate(zip(params, ref)):
+            if p.numel():
+                err = (p.detach().cpu().double() - r.detach()).abs().max()
+                assert err <= 2e-6 * max(1.0, float(r.detach().abs().max())), (step, k, sizes[k], float(err))
+    for k, n in enumerate(sizes):                                          # the float in front of a misaligned view was never written
+        if k % 3 == 1:
+            assert float(base[k][0]) == first[k]
