@@ -234,6 +234,59 @@ def test_large_configs_run(gs, cfg):
     print(f"config {cfg}: N={n} V={V} P={P}")
 
 
+@pytest.mark.parametrize("cfg,rows", [(4, 64), (5, 96)])
+def test_large_configs_vs_c_oracle(gs, cfg, rows):
+    """Configs 4 (3 M Gaussians, 1080p) and 5 (10 M, 3840 x 2160) against the plain-C double-precision oracle, forward + backward.
+    (1) Two windows of full width (the principal point shifted, like the CPU baseline's crop) with ALL the Gaussians -- the centre
+    rows, where the scene is densest, and rows near the top edge, where |v - cy| is largest and float32 pixel offsets are coarsest --
+    on which the float32 oracle (oracle/torch_port.py in float32 = the reference's own arithmetic) also runs: it calibrates the
+    bounds (a scene three times as dense as config 3 has three times its flips).  (2) The FULL frame: visible count exact, pair count
+    within the knife-edge radii, image and the six gradients within SURVEY 8c / the windows' calibration (flip densities and
+    relative gradient errors carry over; the float32 oracle cannot run the full frames)."""
+    import time
+    from oracle import c_oracle
+    s = scenes.synthetic_scene(cfg)
+    H, W = s["H"], s["W"]
+    full = (H, W, s["fx"], s["fy"], s["cx"], s["cy"])
+    rng = np.random.default_rng(cfg)
+    cals_img, cals_g = [], []
+    for what, y0 in (("centre window", (H - rows) // 2), ("edge window", H // 16), ("full frame", None)):
+        cam = full if y0 is None else (rows, W, s["fx"], s["fy"], s["cx"], s["cy"] - y0)
+        w = rng.uniform(0, 1, (cam[0], cam[1], 3)).astype(np.float32)
+        p = {k: torch.tensor(s[k], device=DEV).requires_grad_(True) for k in NAMES}
+        img = gs.render_gaussians(*[p[k] for k in NAMES], torch.eye(4, device=DEV), *cam)
+        stats = gs.render_stats(img)
+        (img * torch.tensor(w, device=DEV)).sum().backward()
+        got_img = img.detach().cpu().numpy()
+        got = {k: p[k].grad.cpu().numpy() for k in NAMES}
+        del p, img
+        torch.cuda.empty_cache()
+        t0 = time.time()
+        st, ref, g, (V, P) = c_oracle.render(s, *cam, grad_image=w.astype(np.float64))
+        print(f"config {cfg} {what}: C oracle {time.time() - t0:.1f} s, V={V} P={P}; kernel V={stats[1]} P={stats[2]}")
+        assert st == 0 and V > 0
+        if y0 is not None:
+            t0 = time.time()
+            img32, g32 = _oracle_run(s, torch.eye(4), cam, w, torch.float32)
+            print(f"config {cfg}: float32 oracle on the {what}: {time.time() - t0:.1f} s")
+            cal_img, cal_g = util.image_errors(img32, ref), {k: util.grad_errors(g32[k], g[k]) for k in NAMES}
+            cals_img.append(cal_img)
+            cals_g.append(cal_g)
+            del img32, g32
+        else:
+            # the full frame is held to the worse of the two windows (bulk fraction, gradient errors) and to their pooled flip density
+            cal_img = {"bad": max(c["bad"] for c in cals_img), "big": sum(c["big"] for c in cals_img), "n": sum(c["n"] for c in cals_img),
+                       "max": max(c["max"] for c in cals_img), "mean": max(c["mean"] for c in cals_img)}
+            cal_g = {k: {"l2": max(c[k]["l2"] for c in cals_g), "mx": max(c[k]["mx"] for c in cals_g)} for k in NAMES}
+            slack = _knife_edge_pairs(cfg, ulps=64.0)[0]       # (the float64 oracle's own radii against fp32's: see test_full_frame_parity_vs_c_oracle)
+            assert stats[1] == V and abs(stats[2] - P) <= slack, (stats, V, P, slack)
+        util.check_image(got_img, ref, cal=cal_img, what=f"config {cfg} {what} image")
+        for k in NAMES:
+            assert np.count_nonzero(g[k]) > 0
+            util.check_grad(got[k], g[k], k, cal=cal_g[k])
+        del ref, g, got, got_img
+
+
 def test_wide_image_with_more_than_16384_lists(gs):
     """2304 x 1096 pixels = 144 x 137 = 19 728 half-tile lists: the list planning takes its multi-round path and the coarse
     bins number 309.  Image and gradients against the C oracle (double precision)."""
