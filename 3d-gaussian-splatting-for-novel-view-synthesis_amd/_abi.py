@@ -14,7 +14,7 @@ GSPLAT_OK = 0
 GSPLAT_SCENE_OK = 0
 GSPLAT_SCENE_ALL_CULLED = 10
 GSPLAT_SCENE_ALL_OFFSCREEN = 11
-ABI_VERSION = 7
+ABI_VERSION = 8
 GSPLAT_PROJECT_COLOUR_FUSED = 1
 GSPLAT_PROJECT_COUNTS_MAPPED = 2
 GSPLAT_PROJECT_SAVE_SH_JACOBIAN = 4
@@ -91,6 +91,8 @@ SIGNATURES = {
     "gsplat_clip_grad_norm": (_INT, [_I64, _VP, C.c_float, _VP, _VP, _VP]),
     "gsplat_adam_step": (_INT, [_I64, _VP, _VP, _VP, _VP, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, _VP, _VP]),
     "gsplat_adam_step_multi": (_INT, [C.c_int32, C.POINTER(AdamGroup), C.c_float, C.c_float, C.c_float, _VP]),
+    "gsplat_backward_adam_rest": (_INT, [_PG, _VP, _PV, _VP, _I64, _I64, _VP, _PGG, _VP, _I64, C.c_int32, C.POINTER(AdamGroup), C.c_float, C.c_float,
+                                         C.c_float, _VP]),
 }
 
 _lib = None

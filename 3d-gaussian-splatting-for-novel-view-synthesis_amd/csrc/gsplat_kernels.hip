@@ -21,6 +21,7 @@
 #include <algorithm>
 
 #include "gs_body.h"
+#include "gs_adam.h"
 
 using namespace gsm;
 
@@ -241,6 +242,43 @@ __device__ __forceinline__ void unstage_rows(float* __restrict__ g, const float*
             *reinterpret_cast<f4*>(dst + piece * 4) = *reinterpret_cast<const f4*>(lds + piece * 4);
         } else if (piece * 4 < total) {
             for (int k = piece * 4; k < total; ++k) dst[k] = lds[k];
+        }
+    }
+}
+
+// The rows of a wave's R-float gradients (in LDS, as unstage_rows would write them) applied to the parameter instead: one Adam step
+// of rows [row0, row0 + 64) of p with the moments m, v -- 16-byte pieces, the same lanes reading and writing them.
+// counts / capacity: the frame's device counters and the pair capacity it was queued with -- a frame that outgrew its buffers (its
+// gradients are garbage and the host will render it again) or that has nothing on screen (the host will raise the reference's
+// exception) must not step anything: the guard is on the device because the host has not looked at the counters yet.
+struct AdamRest { float* p; float* m; float* v; AdamStep k; const void* counts; long long capacity; };
+typedef float fv4 __attribute__((ext_vector_type(4)));
+template <int R>
+__device__ __forceinline__ void adam_rows(const AdamRest& a, const float* __restrict__ lds, int64_t row0, int64_t n, int lane) {
+    const int64_t left = n - row0;
+    const int total = (int)(left < 64 ? left : 64) * R;
+    float* __restrict__ P = a.p + row0 * R; float* __restrict__ M = a.m + row0 * R; float* __restrict__ V = a.v + row0 * R;
+    constexpr int PIECES = 64 * R / 4;
+#pragma unroll
+    for (int it = 0; it < (PIECES + 63) / 64; ++it) {
+        const int piece = it * 64 + lane;
+        if (piece * 4 + 3 < total) {
+            fv4 p = *reinterpret_cast<const fv4*>(P + piece * 4), g = *reinterpret_cast<const fv4*>(lds + piece * 4);
+            fv4 m = __builtin_nontemporal_load(reinterpret_cast<const fv4*>(M + piece * 4)), v = __builtin_nontemporal_load(reinterpret_cast<const fv4*>(V + piece * 4));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float pc = p[c], gc = g[c], mc = m[c], vc = v[c];
+                adam_one(pc, gc, mc, vc, 1.0f, false, a.k.step_size, a.k.b1, a.k.b2, a.k.inv_sqrt_bc2, a.k.eps);
+                p[c] = pc; m[c] = mc; v[c] = vc;
+            }
+            __builtin_nontemporal_store(m, reinterpret_cast<fv4*>(M + piece * 4));
+            __builtin_nontemporal_store(v, reinterpret_cast<fv4*>(V + piece * 4));
+            *reinterpret_cast<fv4*>(P + piece * 4) = p;
+        } else if (piece * 4 < total) {
+            for (int k = piece * 4; k < total; ++k) {
+                float gk = lds[k];
+                adam_one(P[k], gk, M[k], V[k], 1.0f, false, a.k.step_size, a.k.b1, a.k.b2, a.k.inv_sqrt_bc2, a.k.eps);
+            }
         }
     }
 }
@@ -2120,10 +2158,14 @@ struct ShEmitLds {
 
 // JAC (fused inputs): the forward left d rgb / d logit and d logit / d position in project_state (GSPLAT_PROJECT_SAVE_SH_JACOBIAN),
 // so the 192 bytes of SH coefficients are not read again: 48 instead of 192 bytes per visible Gaussian, and no dY accumulators.
-template <bool FUSED, bool JAC = false>
+// ADAM (fused inputs, saved Jacobian, not factored): the 45 f_rest gradients of a Gaussian are not written: the rows are stepped in
+// place (adam_rows) -- the 192 of the 236 gradient bytes per Gaussian neither leave this kernel nor come back into the optimiser's.
+template <bool FUSED, bool JAC = false, bool ADAM = false>
 __global__ __launch_bounds__(64) void project_backward_kernel(gsplat_gaussians g, const Camera* __restrict__ camp, ViewK vk,
                                                               const uint32_t* __restrict__ tiles, const float* __restrict__ grad2d,
-                                                              gsplat_gaussian_grads out, bool factored, const float* __restrict__ kj_in) {
+                                                              gsplat_gaussian_grads out, bool factored, const float* __restrict__ kj_in,
+                                                              AdamRest ar) {
+    static_assert(!ADAM || (FUSED && JAC), "the in-place step needs the direct path");
     // DIRECT (fused inputs, saved Jacobian): nothing is staged IN (the 44 bytes of geometry are loaded by the lanes), and of the
     // gradients only the 45 f_rest rows go OUT through LDS (the rows of 1 / 3 / 4 floats are stored by the lanes): 11 520 B per
     // wave instead of 15 104 -> 14 waves per CU instead of 10.
@@ -2213,7 +2255,12 @@ __global__ __launch_bounds__(64) void project_backward_kernel(gsplat_gaussians g
         }
         if (!factored) {
             __syncthreads();
-            unstage_rows<45>(out.f_rest, s_rest, row0, g.n, lane);
+            if (ADAM) {
+                const DevCounts* cnt = reinterpret_cast<const DevCounts*>(ar.counts);
+                if (cnt->n_visible > 0 && cnt->n_binned <= ar.capacity) adam_rows<45>(ar, s_rest, row0, g.n, lane);      // (uniform)
+            } else {
+                unstage_rows<45>(out.f_rest, s_rest, row0, g.n, lane);
+            }
         }
         return;
     }
@@ -2651,8 +2698,8 @@ int gsplat_rasterize_backward(int64_t n, int64_t n_binned, const gsplat_view* v,
     return GSPLAT_OK;
 }
 
-int gsplat_project_backward(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, const void* project_state,
-                            const float* grad2d, const gsplat_gaussian_grads* out, int32_t flags, void* stream_) {
+static int project_backward_impl(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, const void* project_state,
+                                 const float* grad2d, const gsplat_gaussian_grads* out, int32_t flags, void* stream_, const AdamRest* ar) {
     bool fused = false;
     int rc = check_gaussians(g, &fused);
     if (rc) return rc;
@@ -2662,20 +2709,33 @@ int gsplat_project_backward(const gsplat_gaussians* g, const float* c2w, const g
     if (!out->pos || !out->opacity_raw) return fail(GSPLAT_ERR_BAD_ARG, "grad pos / opacity_raw is NULL");
     // fused inputs, f_dc and f_rest NULL, color given: hand out the colour-logit gradients instead of the SH gradients
     const bool factored = fused && !out->f_dc && !out->f_rest;
-    if (fused && !factored && !(out->scale_raw && out->q_raw && out->f_dc && out->f_rest)) return fail(GSPLAT_ERR_BAD_ARG, "fused grads incomplete");
+    if (ar && !(fused && !factored && (flags & GSPLAT_BACKWARD_SH_JACOBIAN)))
+        return fail(GSPLAT_ERR_BAD_ARG, "the in-place f_rest step needs fused inputs, the saved SH Jacobian and SH gradients (no factored exchange)");
+    if (fused && !factored && !(out->scale_raw && out->q_raw && out->f_dc && (out->f_rest || ar))) return fail(GSPLAT_ERR_BAD_ARG, "fused grads incomplete");
     if (factored && !(out->scale_raw && out->q_raw)) return fail(GSPLAT_ERR_BAD_ARG, "fused grads incomplete");
     if (!fused && !(out->color && out->sigma)) return fail(GSPLAT_ERR_BAD_ARG, "grad color / sigma is NULL");
     hipStream_t st = (hipStream_t)stream_;
     ProjectState ps = carve_project((void*)project_state, g->n, n_lists(v));
     const ViewK vk = make_viewk(*v);
-    if (fused && (flags & GSPLAT_BACKWARD_SH_JACOBIAN))
-        hipLaunchKernelGGL((project_backward_kernel<true, true>), dim3(blocks64(g->n)), dim3(64), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out, factored, ps.kj);
+    const AdamRest none = {nullptr, nullptr, nullptr, {0.f, 0.f, 0.f, 0.f, 0.f}, nullptr, 0};
+    if (ar) {
+        AdamRest a = *ar;
+        a.counts = ps.counts;
+        hipLaunchKernelGGL((project_backward_kernel<true, true, true>), dim3(blocks64(g->n)), dim3(64), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out, false, ps.kj, a);
+    }
+    else if (fused && (flags & GSPLAT_BACKWARD_SH_JACOBIAN))
+        hipLaunchKernelGGL((project_backward_kernel<true, true>), dim3(blocks64(g->n)), dim3(64), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out, factored, ps.kj, none);
     else if (fused)
-        hipLaunchKernelGGL((project_backward_kernel<true, false>), dim3(blocks64(g->n)), dim3(64), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out, factored, nullptr);
+        hipLaunchKernelGGL((project_backward_kernel<true, false>), dim3(blocks64(g->n)), dim3(64), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out, factored, nullptr, none);
     else
-        hipLaunchKernelGGL((project_backward_kernel<false, false>), dim3(blocks64(g->n)), dim3(64), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out, false, nullptr);
+        hipLaunchKernelGGL((project_backward_kernel<false, false>), dim3(blocks64(g->n)), dim3(64), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out, false, nullptr, none);
     LAUNCH_CHECK("project_backward_kernel");
     return GSPLAT_OK;
+}
+
+int gsplat_project_backward(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, const void* project_state,
+                            const float* grad2d, const gsplat_gaussian_grads* out, int32_t flags, void* stream_) {
+    return project_backward_impl(g, c2w, v, project_state, grad2d, out, flags, stream_, nullptr);
 }
 
 // ---- one call per direction (include/gsplat_mi355x.h: "composite entries") ----------------------------------------------
@@ -2725,9 +2785,9 @@ int gsplat_forward_deferred(const gsplat_gaussians* g, const float* c2w, const g
     return gsplat_rasterize_forward(g->n, pair_capacity, v, base + f.project_state, base + f.bin_state, image, accum, grad2d, stream_);
 }
 
-int gsplat_backward(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, void* frame, int64_t frame_bytes,
-                    int64_t pair_capacity, const float* grad_image, const gsplat_gaussian_grads* out, float* grad_logit,
-                    void* det_scratch, int64_t det_scratch_bytes, int32_t flags, void* stream_) {
+static int backward_impl(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, void* frame, int64_t frame_bytes,
+                         int64_t pair_capacity, const float* grad_image, const gsplat_gaussian_grads* out, float* grad_logit,
+                         void* det_scratch, int64_t det_scratch_bytes, int32_t flags, void* stream_, const AdamRest* ar) {
     if (!g || !v) return fail(GSPLAT_ERR_BAD_ARG, "gaussians / view is NULL");
     int rc = check_view(v);
     if (rc) return rc;
@@ -2746,9 +2806,33 @@ int gsplat_backward(const gsplat_gaussians* g, const float* c2w, const gsplat_vi
     }
     if (both || (flags & GSPLAT_BACKWARD_PHASE_PROJECT)) {
         if (!out) return fail(GSPLAT_ERR_BAD_ARG, "grads is NULL");
-        if ((rc = gsplat_project_backward(g, c2w, v, base + f.project_state, grad2d, out, flags & GSPLAT_BACKWARD_SH_JACOBIAN, stream_))) return rc;
+        if ((rc = project_backward_impl(g, c2w, v, base + f.project_state, grad2d, out, flags & GSPLAT_BACKWARD_SH_JACOBIAN, stream_, ar))) return rc;
     }
     return GSPLAT_OK;
+}
+
+int gsplat_backward(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, void* frame, int64_t frame_bytes,
+                    int64_t pair_capacity, const float* grad_image, const gsplat_gaussian_grads* out, float* grad_logit,
+                    void* det_scratch, int64_t det_scratch_bytes, int32_t flags, void* stream_) {
+    return backward_impl(g, c2w, v, frame, frame_bytes, pair_capacity, grad_image, out, grad_logit, det_scratch, det_scratch_bytes, flags,
+                         stream_, nullptr);
+}
+
+int gsplat_backward_adam_rest(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, void* frame, int64_t frame_bytes,
+                              int64_t pair_capacity, const float* grad_image, const gsplat_gaussian_grads* out, void* det_scratch,
+                              int64_t det_scratch_bytes, int32_t flags, const gsplat_adam_group* f_rest, float beta1, float beta2, float eps,
+                              void* stream_) {
+    if (!g || !f_rest) return fail(GSPLAT_ERR_BAD_ARG, "gaussians / f_rest update is NULL");
+    if (flags & (GSPLAT_BACKWARD_PHASE_RASTER | GSPLAT_BACKWARD_PHASE_PROJECT)) return fail(GSPLAT_ERR_BAD_ARG, "the in-place step runs the whole backward pass");
+    if (f_rest->n != g->n * 45 || f_rest->step < 1 || !f_rest->param || !f_rest->exp_avg || !f_rest->exp_avg_sq || f_rest->grad_scale ||
+        f_rest->param != g->f_rest)
+        return fail(GSPLAT_ERR_BAD_ARG, "f_rest update: param must be the f_rest the frame was rendered from (45 n values), moments given, no grad_scale");
+    if ((reinterpret_cast<uintptr_t>(f_rest->param) | reinterpret_cast<uintptr_t>(f_rest->exp_avg) | reinterpret_cast<uintptr_t>(f_rest->exp_avg_sq)) & 15u)
+        return fail(GSPLAT_ERR_BAD_ARG, "f_rest update: 16-byte aligned arrays");
+    const double bc1 = 1.0 - pow((double)beta1, (double)f_rest->step), bc2 = 1.0 - pow((double)beta2, (double)f_rest->step);
+    const AdamRest ar = {f_rest->param, f_rest->exp_avg, f_rest->exp_avg_sq,
+                         {(float)((double)f_rest->lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps}, nullptr, (long long)pair_capacity};
+    return backward_impl(g, c2w, v, frame, frame_bytes, pair_capacity, grad_image, out, nullptr, det_scratch, det_scratch_bytes, flags, stream_, &ar);
 }
 
 int gsplat_build_sigma(int64_t n, const float* scale_raw, const float* q_raw, float* sigma, void* stream_) {

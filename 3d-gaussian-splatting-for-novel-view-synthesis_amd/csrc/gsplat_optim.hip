@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/gsplat_mi355x.h"
+#include "gs_adam.h"
 
 extern thread_local char gsplat_err_buf[512];
 
@@ -60,17 +61,6 @@ struct AdamGroup {
 struct AdamGroups { AdamGroup g[MAX_GROUPS]; int32_t count; float b1, b2, eps; };
 
 typedef float f4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float adam_one(float& p, float& g, float& m, float& v, float gs, bool scaled, float step_size, float b1, float b2,
-                                          float inv_sqrt_bc2, float eps) {
-    float gi = g;
-    if (scaled) { gi *= gs; g = gi; }                          // clip_grad_norm_ scales the gradient in place
-    const float mi = m + (1.0f - b1) * (gi - m);               // lerp, as torch does
-    const float vi = b2 * v + (1.0f - b2) * gi * gi;
-    m = mi; v = vi;
-    p -= step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
-    return gi;
-}
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamGroups a) {
     int k = 0;

@@ -538,6 +538,17 @@ def set_deterministic(flag=True):
     return old
 
 
+_rest_update = None
+
+
+def set_rest_update(hook):
+    """hook (optim.GaussianAdam.fused_rest_update) or None: while one is installed, the backward pass of a deferred frame rendered
+    from the hook's own f_rest tensor applies the Adam step of f_rest inside the projection backward (gsplat_backward_adam_rest) and
+    returns no gradient for it."""
+    global _rest_update
+    _rest_update = hook
+
+
 def set_sh_gradient_sink(sink):
     """sink: object with .add(grad_logit[N,3], eye[3] device tensor), or None to restore the ordinary backward."""
     global _sh_sink
@@ -565,7 +576,11 @@ def _backward_impl(fr, grad_image):
     det = None
     if _deterministic:
         det = _ws.get_scratch(dev, lib.gsplat_rasterize_backward_scratch_bytes(fr.n, fr.n_pairs), (dev.type, dev.index, stream.cuda_stream))
-    out = _flat_like({k: v for k, v in ins.items() if not (factored and k in ("f_dc", "f_rest"))})
+    wants_stages = _timer is not None and _timer.wants(_BACKWARD_STAGES)
+    upd = _rest_update
+    fold_rest = (upd is not None and fr.arena is not None and not factored and not wants_stages and fr.fused and fr.sh_jacobian
+                 and not upd.applied and fr.src_ptrs is not None and upd.matches(ins["f_rest"], fr.src_ptrs[1]))
+    out = _flat_like({k: v for k, v in ins.items() if not ((factored and k in ("f_dc", "f_rest")) or (fold_rest and k == "f_rest"))})
     gg = _abi.GaussianGrads(_p(out["pos"]), _p(out["opacity_raw"]), _p(None if factored else out.get("color")), _p(out.get("sigma")),
                             _p(out.get("scale_raw")), _p(out.get("q_raw")), _p(out.get("f_dc")), _p(out.get("f_rest")))
     jac = _abi.GSPLAT_BACKWARD_SH_JACOBIAN if fr.sh_jacobian else 0
@@ -575,7 +590,13 @@ def _backward_impl(fr, grad_image):
         fr.dirty = True                        # a second backward through the same graph must not reuse a dirty buffer
         args = (fr.gaussians, fr.c2w.data_ptr(), fr.view, fr.arena.data_ptr(), fr.arena.numel(), fr.n_pairs, gi.data_ptr(), gg)
         dargs = (det.data_ptr() if det is not None else None, det.numel() if det is not None else 0)
-        wants_stages = _timer is not None and _timer.wants(_BACKWARD_STAGES)
+        if fold_rest:
+            # the Adam step of f_rest inside the projection backward: its 192 bytes of gradient per Gaussian are never written
+            group, b1, b2, eps = upd.begin()
+            _abi.check(lib.gsplat_backward_adam_rest(*args, *dargs, jac | dirty, C.byref(group), b1, b2, eps, st), "gsplat_backward_adam_rest")
+            composite_calls["backward"] += 1
+            out["f_rest"] = None
+            return out
         if factored or wants_stages:
             glogit = torch.empty((fr.n, 3), dtype=torch.float32, device=dev) if factored else None
             with _stage("raster_backward"):

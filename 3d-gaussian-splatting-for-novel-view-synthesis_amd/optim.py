@@ -5,11 +5,12 @@ learning-rate schedule (:446-457), `clip_grad_norm_(model.pos, max_norm=1.0)` (:
 `GaussianAdam` takes torch-style param groups; `step()` runs ONE fused HIP kernel for all of them (csrc/gsplat_optim.hip); the
 clip coefficient is computed and applied on the device, so a training step has no host synchronisation here.
 """
+import contextlib
 import ctypes as C
 
 import torch
 
-from . import _abi
+from . import _abi, ops
 from .ops import _p, _stage, _stream_ptr
 
 
@@ -34,6 +35,32 @@ def reference_param_groups(model, position_lr_init=0.00016, feature_lr=0.0025, o
             {'params': [model.f_rest], 'lr': feature_lr / 20.0, 'name': 'f_rest'},
             {'params': [model.scale_raw], 'lr': scaling_lr, 'name': 'scale'},
             {'params': [model.q_raw], 'lr': rotation_lr, 'name': 'rotation'}]
+
+
+class _RestUpdate:
+    """What ops._backward_impl needs to fold the Adam step of one parameter (f_rest) into the backward pass."""
+
+    def __init__(self, opt, param, lr):
+        self.opt, self.param, self.lr, self.applied = opt, param, lr, False
+
+    def matches(self, f_rest32, src_ptr):
+        p = self.param
+        return (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and src_ptr == p.data_ptr()
+                and f_rest32.data_ptr() == p.data_ptr() and p.data_ptr() % 16 == 0)
+
+    def begin(self):
+        st = self.opt._state(self.param)
+        st['step'] += 1
+        self.applied = True
+        group = _abi.AdamGroup(self.param.numel(), _p(self.param).value, None, _p(st['exp_avg']).value, _p(st['exp_avg_sq']).value,
+                               float(self.lr), int(st['step']), None)
+        return group, float(self.opt.betas[0]), float(self.opt.betas[1]), float(self.opt.eps)
+
+    def rollback(self):
+        """The frame turned out to have outgrown its buffers (or to be off screen): the kernel stepped nothing, so nothing counts."""
+        if self.applied:
+            self.opt._state(self.param)['step'] -= 1
+            self.applied = False
 
 
 class GaussianAdam:
@@ -66,6 +93,20 @@ class GaussianAdam:
             st = self.state[p] = {'step': 0, 'exp_avg': torch.zeros_like(p, memory_format=torch.contiguous_format),
                                   'exp_avg_sq': torch.zeros_like(p, memory_format=torch.contiguous_format)}
         return st
+
+    @contextlib.contextmanager
+    def fused_rest_update(self, param):
+        """For an iteration of ONE view rendered inside ops.deferred_checks(): the backward pass applies this optimiser's step of
+        `param` (the model's f_rest: 81 % of all parameters) as the gradient is formed, param.grad stays None and step() skips it.
+        Yields the hook: call hook.rollback() when the frame's checks fail afterwards (ops.PairCapacityExceeded, off-screen) -- the
+        kernel itself stepped nothing in that case."""
+        lr = next(g['lr'] for g in self.param_groups if any(p is param for p in g['params']))
+        hook = _RestUpdate(self, param, lr)
+        ops.set_rest_update(hook)
+        try:
+            yield hook
+        finally:
+            ops.set_rest_update(None)
 
     @torch.no_grad()
     def clip_grad_norm_(self, param, max_norm=1.0):

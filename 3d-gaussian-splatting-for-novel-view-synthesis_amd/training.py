@@ -54,6 +54,10 @@ class TrainConfig:
     # latency-bound front of view k + 1 (projection, binning) runs beside the VALU-bound rasterisation of view k: ~10 % per view
     # at config 3.  Gradients accumulate in view order either way.
     view_streams: int = 2
+    # not a reference hyper-parameter either: an iteration of ONE view on one process applies the Adam step of f_rest (81 % of the
+    # parameters) inside the projection backward -- its gradient is neither written nor read back by the optimiser (0.07 ms of 1.0
+    # at config 3); the same arithmetic as the optimiser's kernel, bit for bit.
+    fold_rest_step: bool = True
 
 
 _side_streams = {}           # per device: the two streams the views of an iteration alternate between (TrainConfig.view_streams)
@@ -124,8 +128,11 @@ class Trainer:
             # no host synchronisation per view: the renders size their buffers from earlier frames, the per-frame checks
             # (off-screen exception, buffer capacity) are made ONCE, after the last backward is queued
             pass_error = None
+            fold = c.fold_rest_step and world == 1 and len(views) == 1
+            rest_hook = None
             try:
-                with ops.deferred_checks() as checks, (exchange if exchange is not None else contextlib.nullcontext()):
+                with ops.deferred_checks() as checks, (exchange if exchange is not None else contextlib.nullcontext()), \
+                        (self.optimizer.fused_rest_update(m.f_rest) if fold else contextlib.nullcontext()) as rest_hook:
                     side = self._view_streams(dev) if (c.view_streams > 1 and len(views) > 1 and world == 1) else ()     # (one process: the
                     # exchange's collectives of a data-parallel pass stay on the caller's stream)
                     main = torch.cuda.current_stream(dev) if side else None
@@ -164,6 +171,8 @@ class Trainer:
                 status = dp.STATUS_REDO           # a view outgrew the buffers: this pass's gradients are invalid (capacity now raised)
             except Exception as e:                # the reference's off-screen Exception (render.py:235-236), or anything else
                 status, err = (dp.STATUS_OFFSCREEN if str(e) == ops.OFFSCREEN_MSG else dp.STATUS_ERROR), e
+            if status != dp.STATUS_OK and rest_hook is not None:
+                rest_hook.rollback()              # (the kernel stepped nothing for a frame that overflowed or is off screen: nothing counts)
             if pass_error is not None:            # an exception inside the render loop itself (a frame that waited for its counters, a device error)
                 err = pass_error
                 status = dp.STATUS_OFFSCREEN if str(err) == ops.OFFSCREEN_MSG else dp.STATUS_ERROR
@@ -187,9 +196,10 @@ class Trainer:
         else:
             raise RuntimeError("the pair buffers overflowed four times in a row")
         names = dp.PARAM_NAMES
+        folded = rest_hook is not None and rest_hook.applied      # f_rest was stepped inside the backward pass: no gradient, no second step
         for k in names:
             p = getattr(m, k)
-            if p.grad is None:
+            if p.grad is None and not (folded and p is m.f_rest):
                 p.grad = torch.zeros_like(p)
         self.optimizer.clip_grad_norm_(m.pos, max_norm=1.0)
         self.optimizer.step()

@@ -635,7 +635,7 @@ def single_gpu_extras(gs, ops, params, cam, cam_args, dev, fence):
         it[0] += 1
     for _ in range(3):
         train_step()
-    out["train_step"] = {"workload": "config 3, Trainer.step: fused render + fused L1/SSIM loss + backward + clip + fused Adam, one view",
+    out["train_step"] = {"workload": "config 3, Trainer.step: fused render + fused L1/SSIM loss + backward (the Adam step of f_rest inside it) + clip + fused Adam, one view",
                          "ms": timed(train_step, 20, fence)}
     del trainer, model
     # -- config 4 of BASELINE.json on ONE GPU: the 3 M-Gaussian scene, a training iteration over 8 orbit views (what 8 ranks with one

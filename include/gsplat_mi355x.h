@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define GSPLAT_ABI_VERSION 7
+#define GSPLAT_ABI_VERSION 8
 
 /* call status */
 #define GSPLAT_OK 0
@@ -288,6 +288,20 @@ typedef struct gsplat_adam_group {
     const float* grad_scale;      /* nullable device scalar */
 } gsplat_adam_group;
 int gsplat_adam_step_multi(int32_t n_groups, const gsplat_adam_group* groups, float beta1, float beta2, float eps, void* stream);
+
+/* gsplat_backward with the Adam step of f_rest folded into the projection backward: the 45 SH gradients of a Gaussian (192 of the 236
+ * gradient bytes) are applied to f_rest as they are formed -- they are neither written nor read again by the optimiser.  For an
+ * iteration of ONE view (gradients of several views must be added up before a step): f_rest->param must be the f_rest the frame
+ * was rendered from, f_rest->n = 45 n, no grad_scale; out->f_rest is not written (may be NULL); every other gradient as in
+ * gsplat_backward.  Needs fused inputs and GSPLAT_BACKWARD_SH_JACOBIAN (a frame queued without GSPLAT_FRAME_NO_SH_JACOBIAN); both
+ * phases run.  The same arithmetic, instruction for instruction, as gsplat_adam_step on the gradient gsplat_backward would write.
+ * A frame whose pairs outgrew pair_capacity (n_binned > pair_capacity: its gradients are garbage, the caller renders it again) or
+ * that has nothing on screen steps NOTHING: the kernel reads the frame's device counters itself; the caller, once it has read them
+ * too, knows which of the two happened (and must not count the step).                                                          */
+int gsplat_backward_adam_rest(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, void* frame, int64_t frame_bytes,
+                              int64_t pair_capacity, const float* grad_image, const gsplat_gaussian_grads* out, void* det_scratch,
+                              int64_t det_scratch_bytes, int32_t flags, const gsplat_adam_group* f_rest, float beta1, float beta2,
+                              float eps, void* stream);
 
 #ifdef __cplusplus
 }

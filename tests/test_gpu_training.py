@@ -255,6 +255,69 @@ def test_views_on_two_streams_train_like_views_on_one():
         assert torch.equal(out[0][1][k], out[1][1][k]), k
 
 
+def test_adam_step_of_f_rest_inside_the_backward_pass_is_the_optimisers_step():
+    """TrainConfig.fold_rest_step: an iteration of one view applies the Adam step of f_rest inside the projection backward
+    (gsplat_backward_adam_rest).  Same arithmetic as the optimiser's kernel on the gradient the backward would have written: with
+    deterministic gradients every parameter -- and both moments of f_rest -- are bit-identical after three iterations.  A pass that
+    outgrew its pair buffers steps nothing (the kernel reads the frame's counters itself) and is repeated; an off-screen view raises
+    the reference's exception with every parameter untouched."""
+    model_mod = importlib.import_module(PKG + ".model")
+    training = importlib.import_module(PKG + ".training")
+    ops = importlib.import_module(PKG + ".ops")
+    s, views = _scene()
+    one = views[:1]
+    ops.set_deterministic(True)
+    try:
+        res = []
+        for fold in (False, True):
+            model = model_mod.GaussianModel({k: torch.tensor(s[k]) for k in NAMES}, device="cuda:0")
+            tr = training.Trainer(model, training.TrainConfig(densify_until_iter=0, opacity_reset_interval=10 ** 9, fold_rest_step=fold))
+            tr.step(1, one)                                    # (the first frame of a scene waits for its counters: the ordinary backward)
+            calls = ops.composite_calls["backward"]
+            losses = [float(tr.step(it, one)["loss"]) for it in (2, 3, 4)]
+            assert ops.composite_calls["backward"] == calls + 3
+            st = tr.optimizer.state[model.f_rest]
+            assert st['step'] == 4 and (model.f_rest.grad is None) == fold
+            if fold:                                           # an iteration whose buffers are too small: one garbage pass, one good one
+                import types
+                key = ops.capacity_key(torch.device("cuda:0"), types.SimpleNamespace(H=one[0]["H"], W=one[0]["W"]), len(s["pos"]))
+                keep = ops._ws.capacity[key]
+            torch.cuda.synchronize()
+            res.append((losses, {k: getattr(model, k).detach().clone() for k in NAMES}, st['exp_avg'].clone(), st['exp_avg_sq'].clone()))
+            if fold:
+                ops._ws.capacity[key] = 100
+                before = dict(ops.forward_modes)
+                tr.step(5, one)
+                assert ops.forward_modes["deferred"] == before["deferred"] + 2 and tr.optimizer.state[model.f_rest]['step'] == 5
+                folded_after_redo = model.f_rest.detach().clone()
+                ops._ws.capacity[key] = keep
+            else:
+                tr.step(5, one)
+                plain_after = model.f_rest.detach().clone()
+    finally:
+        ops.set_deterministic(False)
+    assert res[0][0] == res[1][0]
+    for k in NAMES:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+    assert torch.equal(res[0][2], res[1][2]) and torch.equal(res[0][3], res[1][3])
+    assert torch.equal(plain_after, folded_after_redo)        # the garbage pass stepped nothing
+    # off screen: the reference's exception, nothing moved
+    g = scenes.case_g10()
+    model = model_mod.GaussianModel({k: torch.tensor(g[k]) for k in NAMES}, device="cuda:0")
+    tr = training.Trainer(model, training.TrainConfig(densify_until_iter=0, opacity_reset_interval=10 ** 9))
+    target = np.random.default_rng(9).uniform(0, 1, (g["H"], g["W"], 3)).astype(np.float32)
+    good = dict(image=target, c2w=g["c2w"], H=g["H"], W=g["W"], fx=g["fx"], fy=g["fy"], cx=g["cx"] + 40.0, cy=g["cy"])
+    tr.step(1, [good])
+    tr.step(2, [good])
+    before = {k: getattr(model, k).detach().clone() for k in NAMES}
+    step_before = tr.optimizer.state[model.f_rest]['step']
+    with pytest.raises(Exception, match="off-screen"):
+        tr.step(3, [dict(good, cx=g["cx"])])
+    torch.cuda.synchronize()
+    assert all(torch.equal(before[k], getattr(model, k).detach()) for k in NAMES)
+    assert tr.optimizer.state[model.f_rest]['step'] == step_before
+
+
 def test_config4_training_iteration():
     """BASELINE.json config 4 as it says: the 3 M-Gaussian scene at 1080p through Trainer.step (render + L1/SSIM loss + backward
     + clip + Adam), two views.  Finite, every parameter moves, and the loss of view 0 equals the oracle's compute_loss of the
