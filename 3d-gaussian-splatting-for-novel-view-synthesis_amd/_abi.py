@@ -87,6 +87,8 @@ SIGNATURES = {
     "gsplat_evaluate_sh_backward": (_INT, [_I64, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "gsplat_loss_scratch_bytes": (_I64, [_I64, C.c_int32, C.c_int32, C.c_int32]),
     "gsplat_loss": (_INT, [_VP, _VP, _I64, C.c_int32, C.c_int32, C.c_float, C.c_float, _VP, _VP, _VP, _VP]),
+    "gsplat_loss_forward": (_INT, [_VP, _VP, _I64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, _VP, _VP, _VP, C.c_int32, _VP]),
+    "gsplat_loss_backward": (_INT, [_VP, _VP, _I64, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, _VP, _VP, _VP, _VP]),
     "gsplat_clip_scratch_bytes": (_I64, []),
     "gsplat_clip_grad_norm": (_INT, [_I64, _VP, C.c_float, _VP, _VP, _VP]),
     "gsplat_adam_step": (_INT, [_I64, _VP, _VP, _VP, _VP, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, _VP, _VP]),

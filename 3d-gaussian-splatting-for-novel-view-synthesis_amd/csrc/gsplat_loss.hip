@@ -79,7 +79,8 @@ static_assert(sizeof(StatsLds) <= 52 * 1024, "three workgroups per CU");
 
 // Sum of the blocks' partial sums in a fixed order (double), by one workgroup: -> values[3] = (l1, 1 - ssim, total)
 __device__ __forceinline__ void finish_sums(const float* __restrict__ partial, int n_blocks, double inv_n, float l1w, float sw,
-                                            float* __restrict__ values, double (*red)[THREADS / 64]) {
+                                            float* __restrict__ values, double (*red)[THREADS / 64], double scale = 1.0,
+                                            float* __restrict__ total_out = nullptr) {
     const int tid = threadIdx.x;
     double a = 0.0, b = 0.0;
     for (int k = tid; k < n_blocks; k += THREADS) { a += (double)partial[2 * k]; b += (double)partial[2 * k + 1]; }
@@ -90,7 +91,8 @@ __device__ __forceinline__ void finish_sums(const float* __restrict__ partial, i
         a = 0.0; b = 0.0;
         for (int k = 0; k < THREADS / 64; ++k) { a += red[0][k]; b += red[1][k]; }
         const double l1 = a * inv_n, sl = 1.0 - b * inv_n;
-        values[0] = (float)l1; values[1] = (float)sl; values[2] = (float)(l1w * l1 + sw * sl);
+        values[0] = (float)(scale * l1); values[1] = (float)(scale * sl); values[2] = (float)(scale * (l1w * l1 + sw * sl));
+        if (total_out) *total_out = values[2];
     }
 }
 
@@ -228,9 +230,11 @@ static_assert(sizeof(GradLds) <= 52 * 1024 + 256, "three workgroups per CU");
 // d(sum S)/dx(q) = (w * dS/dmu1)(q) + 2 x(q) (w * dS/dE11)(q) + y(q) (w * dS/dE12)(q); with the L1 term and the weights -> grad.
 // Block (0, 0, 0) also adds up the partial sums loss_stats_kernel left (values[3]).
 __global__ __launch_bounds__(THREADS) void loss_grad_kernel(const float* __restrict__ pred, const float* __restrict__ target, int H, int W,
-                                                            float l1w, float sw, float inv_n, double inv_n_d, const float* __restrict__ maps,
+                                                            float l1w, float sw, float inv_n_, double inv_n_d, const float* __restrict__ maps,
                                                             const float* __restrict__ partial, float* __restrict__ values,
-                                                            float* __restrict__ grad) {
+                                                            float* __restrict__ grad, const float* __restrict__ upstream) {
+    // upstream (nullable device scalar): d L / d total of the caller's graph -- multiplied in here, not by a pass over the gradient
+    const float inv_n = upstream ? inv_n_ * *upstream : inv_n_;
     __shared__ GradLds s;
     __shared__ double red[2][THREADS / 64];
     const int tid = threadIdx.x;
@@ -284,7 +288,7 @@ __global__ __launch_bounds__(THREADS) void loss_grad_kernel(const float* __restr
             }
         }
     }
-    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+    if (values && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
         finish_sums(partial, (int)(gridDim.x * gridDim.y * gridDim.z), inv_n_d, l1w, sw, values, red);
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
@@ -335,9 +339,9 @@ __global__ __launch_bounds__(THREADS) void loss_grad_kernel(const float* __restr
 
 // value only (no gradient asked for): the sums by a kernel of their own
 __global__ __launch_bounds__(THREADS) void loss_finish_kernel(const float* __restrict__ partial, int n_blocks, double inv_n, float l1w, float sw,
-                                                              float* __restrict__ values) {
+                                                              float* __restrict__ values, double scale, float* __restrict__ total_out) {
     __shared__ double red[2][THREADS / 64];
-    finish_sums(partial, n_blocks, inv_n, l1w, sw, values, red);
+    finish_sums(partial, n_blocks, inv_n, l1w, sw, values, red, scale, total_out);
 }
 
 }  // namespace
@@ -369,13 +373,57 @@ int gsplat_loss(const float* pred, const float* target, int64_t batch, int32_t H
     hipLaunchKernelGGL(loss_stats_kernel, grid, dim3(THREADS), 0, st, pred, target, (int)H, (int)W, partial, maps);
     if (grad_pred)
         hipLaunchKernelGGL(loss_grad_kernel, grid, dim3(THREADS), 0, st, pred, target, (int)H, (int)W, lambda_l1, lambda_ssim, (float)(1.0 / n),
-                           1.0 / n, (const float*)maps, (const float*)partial, values, grad_pred);
+                           1.0 / n, (const float*)maps, (const float*)partial, values, grad_pred, (const float*)nullptr);
     else
         hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(THREADS), 0, st, (const float*)partial, (int)loss_blocks(batch, H, W), 1.0 / n,
-                           lambda_l1, lambda_ssim, values);
+                           lambda_l1, lambda_ssim, values, 1.0, (float*)nullptr);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         snprintf(g_loss_err, sizeof(g_loss_err), "gsplat_loss launch: %s", hipGetErrorString(e));
+        return GSPLAT_ERR_HIP;
+    }
+    return GSPLAT_OK;
+}
+
+/* The same loss in two calls, for a caller whose graph supplies d L / d total only later (an autograd node): the forward leaves the
+ * partial-derivative maps in scratch, the backward multiplies the upstream scalar and `scale` into the gradient it writes -- no pass
+ * over the gradient afterwards, no gradient computed for a value nobody differentiates.                                          */
+int gsplat_loss_forward(const float* pred, const float* target, int64_t batch, int32_t H, int32_t W, float lambda_l1, float lambda_ssim,
+                        float scale, float* values, float* total, void* scratch, int32_t keep_maps, void* stream_) {
+    if (!pred || !target || !values || !scratch || batch <= 0 || H <= 0 || W <= 0 || batch > 65535 || loss_blocks(batch, H, W) > 0x3FFFFFFF) {
+        snprintf(g_loss_err, sizeof(g_loss_err), "gsplat_loss_forward: bad argument");
+        return GSPLAT_ERR_BAD_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream_;
+    float* partial = (float*)scratch;
+    const double n = (double)batch * H * W * 3;
+    const dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, (unsigned)batch);
+    float* maps = keep_maps ? (float*)((char*)scratch + loss_sums_bytes(batch, H, W)) : nullptr;
+    hipLaunchKernelGGL(loss_stats_kernel, grid, dim3(THREADS), 0, st, pred, target, (int)H, (int)W, partial, maps);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(THREADS), 0, st, (const float*)partial, (int)loss_blocks(batch, H, W), 1.0 / n,
+                       lambda_l1, lambda_ssim, values, (double)scale, total);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_loss_err, sizeof(g_loss_err), "gsplat_loss_forward launch: %s", hipGetErrorString(e));
+        return GSPLAT_ERR_HIP;
+    }
+    return GSPLAT_OK;
+}
+
+int gsplat_loss_backward(const float* pred, const float* target, int64_t batch, int32_t H, int32_t W, float lambda_l1, float lambda_ssim,
+                         float scale, const float* upstream, float* grad_pred, void* scratch, void* stream_) {
+    if (!pred || !target || !grad_pred || !scratch || batch <= 0 || H <= 0 || W <= 0 || batch > 65535 || loss_blocks(batch, H, W) > 0x3FFFFFFF) {
+        snprintf(g_loss_err, sizeof(g_loss_err), "gsplat_loss_backward: bad argument");
+        return GSPLAT_ERR_BAD_ARG;
+    }
+    const double n = (double)batch * H * W * 3;
+    const dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, (unsigned)batch);
+    const float* maps = (const float*)((char*)scratch + loss_sums_bytes(batch, H, W));
+    hipLaunchKernelGGL(loss_grad_kernel, grid, dim3(THREADS), 0, (hipStream_t)stream_, pred, target, (int)H, (int)W, lambda_l1, lambda_ssim,
+                       (float)((double)scale / n), 1.0 / n, maps, (const float*)scratch, (float*)nullptr, grad_pred, upstream);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_loss_err, sizeof(g_loss_err), "gsplat_loss_backward launch: %s", hipGetErrorString(e));
         return GSPLAT_ERR_HIP;
     }
     return GSPLAT_OK;

@@ -145,15 +145,15 @@ class Trainer:
                             c2w = torch.as_tensor(v['c2w'], dtype=torch.float32).to(dev)
                             rendered = ops.render_gaussians(m.pos, m.f_dc, m.f_rest, m.opacity_raw, m.scale_raw, m.q_raw, c2w,
                                                             int(v['H']), int(v['W']), float(v['fx']), float(v['fy']), float(v['cx']), float(v['cy']))
-                            loss, vals = losses.compute_loss_device(rendered, image_gt, c.lambda_l1, c.lambda_ssim)
-                            (loss / n_global).backward()
+                            loss, vals = losses.compute_loss_device(rendered, image_gt, c.lambda_l1, c.lambda_ssim, scale=1.0 / n_global)
+                            loss.backward()                            # (loss / batch size: the division is inside the loss kernels)
                             per_view.append(vals)
                     for st in side:
                         main.wait_stream(st)
                     for vals in per_view:                                              # (on the caller's stream, in view order)
                         if side:
                             vals.record_stream(main)
-                        acc += vals / n_global
+                        acc += vals
             except Exception as e:                # single process: nothing to agree on, the exception leaves as it is
                 if world == 1:
                     raise

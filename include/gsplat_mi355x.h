@@ -264,6 +264,14 @@ int gsplat_evaluate_sh_backward(int64_t n, const float* f_dc, const float* f_res
 int64_t gsplat_loss_scratch_bytes(int64_t batch, int32_t H, int32_t W, int32_t with_grad);
 int gsplat_loss(const float* pred, const float* target, int64_t batch, int32_t H, int32_t W, float lambda_l1,
                 float lambda_ssim, float* values, float* grad_pred, void* scratch, void* stream);
+/* The same loss as two calls, for a caller whose graph supplies d L / d total later (an autograd node).  gsplat_loss_forward:
+ * values[3] = scale * (l1, 1 - ssim, total), *total (nullable, device) = values[2]; with keep_maps the partial-derivative maps stay in
+ * scratch (sized with_grad = 1) for gsplat_loss_backward, which writes grad_pred = scale * (*upstream) * d total / d pred
+ * (upstream: device scalar, NULL = 1) -- the upstream factor is multiplied in by the kernel, not by a pass over the gradient.  */
+int gsplat_loss_forward(const float* pred, const float* target, int64_t batch, int32_t H, int32_t W, float lambda_l1,
+                        float lambda_ssim, float scale, float* values, float* total, void* scratch, int32_t keep_maps, void* stream);
+int gsplat_loss_backward(const float* pred, const float* target, int64_t batch, int32_t H, int32_t W, float lambda_l1,
+                         float lambda_ssim, float scale, const float* upstream, float* grad_pred, void* scratch, void* stream);
 
 /* ---- next row 2: the optimiser step of scripts/train.py:394-401, 536-538 ---------------------
  * gsplat_clip_grad_norm = torch.nn.utils.clip_grad_norm_ on one tensor: coef_and_norm[2] (device) receives

@@ -286,7 +286,7 @@ def _toy_trainer_worker(rank, world, port, q, mode):
     ops.render_gaussians = fake_render
     ops.DeferredChecks.verify = fake_verify
     ops.sh_accumulate = lambda pos, eyes, logits, scale: (scale * logits.sum(0), scale * logits.sum(0).repeat(1, 15))
-    losses.compute_loss_device = lambda rendered, gt, a, b: (rendered.sum(), torch.zeros(3))
+    losses.compute_loss_device = lambda rendered, gt, a, b, scale=1.0: (rendered.sum() * scale, torch.zeros(3))
     training.Trainer._new_optimizer = lambda self, lr: Opt()
     model = Model()
     tr = training.Trainer(model, training.TrainConfig(densify_until_iter=0, opacity_reset_interval=10 ** 9))

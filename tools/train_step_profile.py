@@ -20,7 +20,7 @@ USE_TORCH_ADAM = "--torch-adam" in sys.argv
 def step():
     for q in p.values(): q.grad = None
     img = gs.render_gaussians(*args)
-    total = losses._LossFn.apply(img, gt, 0.8, 0.2)[2]
+    total = losses._LossFn.apply(img, gt, 0.8, 0.2)[0]
     total.backward()
     if USE_TORCH_ADAM:
         torch.nn.utils.clip_grad_norm_(m.pos, 1.0); tadam.step()
