@@ -2,7 +2,7 @@
 """profiles/<tag>_sq_counters.txt (tools/sq_counters.sh) -> profiles/valu_config<N>.json: per kernel, VALU wave-instructions per launch and
 the VALU pipeline's busy fraction  SQ_ACTIVE_INST_VALU * 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)  (MI355X_MICROARCH.md: the SQ
 counters count quad-cycles; rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs).
-    python tools/valu_summary.py profiles/r03_v1_sq_counters.txt profiles/valu_config3.json"""
+    python tools/valu_summary.py profiles/r03_v3_sq_counters.txt profiles/valu_config3.json"""
 import json
 import re
 import sys
