@@ -25,6 +25,7 @@ GSPLAT_FRAME_NO_SH_JACOBIAN = 2
 GSPLAT_BACKWARD_PHASE_RASTER = 2
 GSPLAT_BACKWARD_PHASE_PROJECT = 4
 GSPLAT_BACKWARD_GRAD2D_DIRTY = 8
+GSPLAT_BACKWARD_ACCUMULATE = 16
 
 _F = C.POINTER(C.c_float)
 

@@ -229,7 +229,8 @@ __device__ __forceinline__ void stage_rows(float* __restrict__ lds, const float*
     }
 }
 
-template <int R>
+// ACC: the rows are ADDED to what g holds (the gradient of several views summed in place, GSPLAT_BACKWARD_ACCUMULATE)
+template <int R, bool ACC = false>
 __device__ __forceinline__ void unstage_rows(float* __restrict__ g, const float* __restrict__ lds, int64_t row0, int64_t n, int lane) {
     const int64_t left = n - row0;
     const int total = (int)(left < 64 ? left : 64) * R;
@@ -239,9 +240,11 @@ __device__ __forceinline__ void unstage_rows(float* __restrict__ g, const float*
     for (int it = 0; it < (PIECES + 63) / 64; ++it) {
         const int piece = it * 64 + lane;
         if (piece * 4 + 3 < total) {
-            *reinterpret_cast<f4*>(dst + piece * 4) = *reinterpret_cast<const f4*>(lds + piece * 4);
+            f4 v = *reinterpret_cast<const f4*>(lds + piece * 4);
+            if (ACC) { const f4 o = *reinterpret_cast<const f4*>(dst + piece * 4); v = f4{o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w}; }
+            *reinterpret_cast<f4*>(dst + piece * 4) = v;
         } else if (piece * 4 < total) {
-            for (int k = piece * 4; k < total; ++k) dst[k] = lds[k];
+            for (int k = piece * 4; k < total; ++k) dst[k] = ACC ? dst[k] + lds[k] : lds[k];
         }
     }
 }
@@ -2160,12 +2163,15 @@ struct ShEmitLds {
 // so the 192 bytes of SH coefficients are not read again: 48 instead of 192 bytes per visible Gaussian, and no dY accumulators.
 // ADAM (fused inputs, saved Jacobian, not factored): the 45 f_rest gradients of a Gaussian are not written: the rows are stepped in
 // place (adam_rows) -- the 192 of the 236 gradient bytes per Gaussian neither leave this kernel nor come back into the optimiser's.
-template <bool FUSED, bool JAC = false, bool ADAM = false>
+// ACC (fused inputs, saved Jacobian, not factored): every gradient is ADDED to what `out` holds -- the gradients of the views of one
+// iteration summed by the kernel that forms them, instead of a pass of the host's autograd per view (read two, write one).
+template <bool FUSED, bool JAC = false, bool ADAM = false, bool ACC = false>
 __global__ __launch_bounds__(64) void project_backward_kernel(gsplat_gaussians g, const Camera* __restrict__ camp, ViewK vk,
                                                               const uint32_t* __restrict__ tiles, const float* __restrict__ grad2d,
                                                               gsplat_gaussian_grads out, bool factored, const float* __restrict__ kj_in,
                                                               AdamRest ar) {
     static_assert(!ADAM || (FUSED && JAC), "the in-place step needs the direct path");
+    static_assert(!ACC || (FUSED && JAC && !ADAM), "accumulation is built for the direct path");
     // DIRECT (fused inputs, saved Jacobian): nothing is staged IN (the 44 bytes of geometry are loaded by the lanes), and of the
     // gradients only the 45 f_rest rows go OUT through LDS (the rows of 1 / 3 / 4 floats are stored by the lanes): 11 520 B per
     // wave instead of 15 104 -> 14 waves per CU instead of 10.
@@ -2235,6 +2241,24 @@ __global__ __launch_bounds__(64) void project_backward_kernel(gsplat_gaussians g
         }
     }
     if (DIRECT) {
+        if (ACC) {
+            if (vis) {                                      // (a Gaussian that is not visible adds nothing)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) out.pos[i * 3 + k] += go.p[k];
+                out.opacity_raw[i] += go.o_raw;
+                const f4 q0 = *reinterpret_cast<const f4*>(out.q_raw + i * 4);
+                *reinterpret_cast<f4*>(out.q_raw + i * 4) = f4{q0.x + go.qr[0], q0.y + go.qr[1], q0.z + go.qr[2], q0.w + go.qr[3]};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) out.scale_raw[i * 3 + k] += go.sr[k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) out.f_dc[i * 3 + k] += gdc[k];
+            }
+            if (any_vis) {
+                __syncthreads();
+                unstage_rows<45, true>(out.f_rest, s_rest, row0, g.n, lane);
+            }
+            return;
+        }
         if (i < g.n) {                                      // every row is written (zeros for a Gaussian that is not visible)
 #pragma unroll
             for (int k = 0; k < 3; ++k) out.pos[i * 3 + k] = go.p[k];
@@ -2709,6 +2733,9 @@ static int project_backward_impl(const gsplat_gaussians* g, const float* c2w, co
     if (!out->pos || !out->opacity_raw) return fail(GSPLAT_ERR_BAD_ARG, "grad pos / opacity_raw is NULL");
     // fused inputs, f_dc and f_rest NULL, color given: hand out the colour-logit gradients instead of the SH gradients
     const bool factored = fused && !out->f_dc && !out->f_rest;
+    const bool acc = (flags & GSPLAT_BACKWARD_ACCUMULATE) != 0;
+    if (acc && (ar || !(fused && !factored && (flags & GSPLAT_BACKWARD_SH_JACOBIAN))))
+        return fail(GSPLAT_ERR_BAD_ARG, "GSPLAT_BACKWARD_ACCUMULATE needs fused inputs, the saved SH Jacobian and SH gradients (no factored exchange, no in-place step)");
     if (ar && !(fused && !factored && (flags & GSPLAT_BACKWARD_SH_JACOBIAN)))
         return fail(GSPLAT_ERR_BAD_ARG, "the in-place f_rest step needs fused inputs, the saved SH Jacobian and SH gradients (no factored exchange)");
     if (fused && !factored && !(out->scale_raw && out->q_raw && out->f_dc && (out->f_rest || ar))) return fail(GSPLAT_ERR_BAD_ARG, "fused grads incomplete");
@@ -2723,6 +2750,8 @@ static int project_backward_impl(const gsplat_gaussians* g, const float* c2w, co
         a.counts = ps.counts;
         hipLaunchKernelGGL((project_backward_kernel<true, true, true>), dim3(blocks64(g->n)), dim3(64), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out, false, ps.kj, a);
     }
+    else if (acc)
+        hipLaunchKernelGGL((project_backward_kernel<true, true, false, true>), dim3(blocks64(g->n)), dim3(64), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out, false, ps.kj, none);
     else if (fused && (flags & GSPLAT_BACKWARD_SH_JACOBIAN))
         hipLaunchKernelGGL((project_backward_kernel<true, true>), dim3(blocks64(g->n)), dim3(64), 0, st, *g, ps.cam, vk, ps.tiles, grad2d, *out, factored, ps.kj, none);
     else if (fused)
@@ -2806,7 +2835,8 @@ static int backward_impl(const gsplat_gaussians* g, const float* c2w, const gspl
     }
     if (both || (flags & GSPLAT_BACKWARD_PHASE_PROJECT)) {
         if (!out) return fail(GSPLAT_ERR_BAD_ARG, "grads is NULL");
-        if ((rc = project_backward_impl(g, c2w, v, base + f.project_state, grad2d, out, flags & GSPLAT_BACKWARD_SH_JACOBIAN, stream_, ar))) return rc;
+        if ((rc = project_backward_impl(g, c2w, v, base + f.project_state, grad2d, out,
+                                        flags & (GSPLAT_BACKWARD_SH_JACOBIAN | GSPLAT_BACKWARD_ACCUMULATE), stream_, ar))) return rc;
     }
     return GSPLAT_OK;
 }

@@ -58,6 +58,9 @@ class TrainConfig:
     # parameters) inside the projection backward -- its gradient is neither written nor read back by the optimiser (0.07 ms of 1.0
     # at config 3); the same arithmetic as the optimiser's kernel, bit for bit.
     fold_rest_step: bool = True
+    # an iteration of SEVERAL views on one process: the projection backward adds each view's gradients to one buffer itself
+    # (ops.accumulate_grads) instead of autograd's accumulation pass per view -- the same sums in the same order.
+    sum_views_in_kernel: bool = True
 
 
 _side_streams = {}           # per device: the two streams the views of an iteration alternate between (TrainConfig.view_streams)
@@ -131,7 +134,9 @@ class Trainer:
             fold = c.fold_rest_step and world == 1 and len(views) == 1
             rest_hook = None
             try:
+                sum_in_kernel = c.sum_views_in_kernel and world == 1 and len(views) > 1      # the views' gradients summed by the projection backward itself
                 with ops.deferred_checks() as checks, (exchange if exchange is not None else contextlib.nullcontext()), \
+                        (ops.accumulate_grads(m.get_params()) if sum_in_kernel else contextlib.nullcontext()) as grad_acc, \
                         (self.optimizer.fused_rest_update(m.f_rest) if fold else contextlib.nullcontext()) as rest_hook:
                     side = self._view_streams(dev) if (c.view_streams > 1 and len(views) > 1 and world == 1) else ()     # (one process: the
                     # exchange's collectives of a data-parallel pass stay on the caller's stream)
@@ -150,6 +155,8 @@ class Trainer:
                             per_view.append(vals)
                     for st in side:
                         main.wait_stream(st)
+                    if grad_acc is not None:
+                        grad_acc.assign()
                     for vals in per_view:                                              # (on the caller's stream, in view order)
                         if side:
                             vals.record_stream(main)

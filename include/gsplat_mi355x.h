@@ -223,6 +223,9 @@ int gsplat_project_backward(const gsplat_gaussians* g, const float* c2w, const g
 #define GSPLAT_BACKWARD_PHASE_RASTER 2
 #define GSPLAT_BACKWARD_PHASE_PROJECT 4
 #define GSPLAT_BACKWARD_GRAD2D_DIRTY 8
+/* the gradients are ADDED to what `out` holds (the views of one iteration summed by the projection backward itself; the caller
+ * clears or writes the arrays with the first view).  Fused inputs with GSPLAT_BACKWARD_SH_JACOBIAN, all six gradients given.  */
+#define GSPLAT_BACKWARD_ACCUMULATE 16
 int64_t gsplat_frame_bytes(int64_t n, int64_t pair_capacity, const gsplat_view* v, int32_t flags);
 int gsplat_forward_deferred(const gsplat_gaussians* g, const float* c2w, const gsplat_view* v, void* frame,
                             int64_t frame_bytes, int64_t pair_capacity, void* counters, int64_t counters_bytes,

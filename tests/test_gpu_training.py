@@ -242,17 +242,20 @@ def test_views_on_two_streams_train_like_views_on_one():
     ops.set_deterministic(True)
     try:
         out = []
-        for streams in (1, 2):
+        for streams, in_kernel in ((1, False), (2, False), (1, True), (2, True)):      # (in_kernel: the views' gradients summed by the projection
+            #  backward itself, ops.accumulate_grads -- the same sums in the same order as autograd's accumulation)
             model = model_mod.GaussianModel({k: torch.tensor(s[k]) for k in NAMES}, device="cuda:0")
-            tr = training.Trainer(model, training.TrainConfig(densify_until_iter=0, opacity_reset_interval=10 ** 9, view_streams=streams))
+            tr = training.Trainer(model, training.TrainConfig(densify_until_iter=0, opacity_reset_interval=10 ** 9, view_streams=streams,
+                                                              sum_views_in_kernel=in_kernel))
             losses = [float(tr.step(it, views)["loss"]) for it in (1, 2, 3)]
             torch.cuda.synchronize()
             out.append((losses, {k: getattr(model, k).detach().clone() for k in NAMES}))
     finally:
         ops.set_deterministic(False)
-    assert out[0][0] == out[1][0], (out[0][0], out[1][0])
-    for k in NAMES:
-        assert torch.equal(out[0][1][k], out[1][1][k]), k
+    for other in out[1:]:
+        assert out[0][0] == other[0], (out[0][0], other[0])
+        for k in NAMES:
+            assert torch.equal(out[0][1][k], other[1][k]), k
 
 
 def test_adam_step_of_f_rest_inside_the_backward_pass_is_the_optimisers_step():
