@@ -1,5 +1,5 @@
-"""Soak of the host logic around the trainer (not a kernel test): many iterations of Trainer.step with the views on two streams, then the
-same on two ranks over gloo on one GPU.  A stall dumps every thread's stack (faulthandler) and exits."""
+"""Soak of the host logic around the trainer (not a kernel test): many iterations of Trainer.step with four views on two streams, with
+one view (the folded f_rest step), then on two ranks over gloo on one GPU.  A stall dumps every thread's stack (faulthandler) and exits."""
 import datetime, faulthandler, importlib, os, socket, sys, time
 import numpy as np
 import torch
@@ -17,14 +17,14 @@ def scene(nviews):
     return s, views
 
 
-def run(rank, world, port, seconds, log):
+def run(rank, world, port, seconds, log, n_views=4):
     faulthandler.enable()
     model_mod = importlib.import_module(PKG + ".model"); training = importlib.import_module(PKG + ".training")
     if world > 1:
         import torch.distributed as dist
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
         dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
-    s, views = scene(4)
+    s, views = scene(n_views)
     model = model_mod.GaussianModel({k: torch.tensor(s[k]) for k in NAMES}, device="cuda:0")
     tr = training.Trainer(model, training.TrainConfig(densification_interval=50, densify_until_iter=10 ** 9, opacity_reset_interval=300))
     t0 = time.time(); it = 1; last = t0
@@ -38,7 +38,7 @@ def run(rank, world, port, seconds, log):
             last = time.time()
             print(f"world {world}: iteration {it} loss {float(out['loss']):.4f} gaussians {out['gaussians']}", file=log, flush=True)
     if rank == 0:
-        print(f"world {world}: {it - 1} iterations in {time.time() - t0:.0f} s, no stall", file=log, flush=True)
+        print(f"world {world}, {n_views} view(s) per iteration: {it - 1} iterations in {time.time() - t0:.0f} s, no stall", file=log, flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.barrier(); dist.destroy_process_group()
@@ -50,7 +50,8 @@ def _worker(rank, world, port, seconds):
 
 if __name__ == "__main__":
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 40
-    run(0, 1, 0, seconds, sys.stdout)
+    run(0, 1, 0, seconds, sys.stdout)                    # four views: two streams, gradients summed by the projection backward
+    run(0, 1, 0, seconds / 2, sys.stdout, n_views=1)     # one view: the Adam step of f_rest inside the backward pass
     import torch.multiprocessing as mp
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
     ctx = mp.get_context("spawn")
